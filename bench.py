@@ -1,0 +1,227 @@
+#!/usr/bin/env python
+"""Benchmark of the FILM hot path on MI355X:  interpolated 1080p frames / second.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one mid-frame of a 1920x1080 frame pair through the tiled path of the reference CLI
+(`--align 64 --block_height 2 --block_width 2`, eval/interpolator_test.py:57-70 -> four 960x540
+patches, each padded to 960x576, eval/interpolator.py:192-206) - BASELINE.json configs[2], the
+configuration the metric is quoted on.  Frames are resident in HBM before the timed region; pad /
+patch / crop / stitch on the device are inside it.  Each rank (= one GPU) interpolates its own
+frame pairs: no collective on the data path, weights are broadcast once over RCCL before timing
+("scaling": "weak").
+
+Extra objects in the JSON line:
+  roofline     fp32-MFMA roofline of the dominant kernel class (conv_igemm): algorithmic conv FLOPs of
+               one forward / summed duration of its conv launches, measured with hipEvents around
+               every launch on the launch stream (engine profile mode), vs 157.3 TFLOP/s.
+  cpu_baseline the CPU oracle (PyTorch-CPU/oneDNN + numpy restatement of the TF graph, kind "port")
+               timed on this host's cores on a bounded sample (one 256x256 pair), converted to
+               1080p-tiled frames/s by the exact conv-FLOP ratio.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'frame-interpolation_amd')
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+CONV_FLOP_PER_PIXEL = 4246240.6875  # sum over the 171 convs, per padded input pixel
+WARP_BYTES_PER_PIXEL = 5201.58      # 22 warps, read once + flow + write once
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # name: (H, W, align, block_shape, padded tile (h, w), tiles)
+    '1080p_2x2': (1080, 1920, 64, [2, 2], (576, 960), 4),
+    '256': (256, 256, 64, None, (256, 256), 1),
+    'vimeo': (256, 448, 64, None, (256, 448), 1),
+    'photos': (768, 1024, 64, None, (768, 1024), 1),
+}
+
+
+def synth_pair(h, w, seed):
+    """smooth random image (uniform noise, 9x9 box filter), second frame = first
+    shifted by (3,-2) px + sigma 0.01 noise, so that the flows are non-trivial."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((h + 8, w + 8, 3), dtype=np.float32)
+    c = np.cumsum(np.cumsum(np.pad(x, ((1, 0), (1, 0), (0, 0))), axis=0, dtype=np.float64), axis=1)
+    k = 9
+    box = (c[k:, k:] - c[:-k, k:] - c[k:, :-k] + c[:-k, :-k]) / (k * k)
+    x0 = box[:h, :w].astype(np.float32)
+    x0 = (x0 - x0.min()) / max(float(x0.max() - x0.min()), 1e-6)
+    x1 = np.roll(x0, (3, -2), axis=(0, 1)) + rng.normal(0, 0.01, x0.shape).astype(np.float32)
+    return x0[None], x1[None].astype(np.float32)
+
+
+def cpu_baseline(weights):
+    """Times the oracle on the host cores: one 256x256 pair of the published net (0.278 TFLOP)."""
+    from oracle import film_oracle as fo
+    ncores = os.cpu_count() or 1
+    torch.set_num_threads(ncores)
+    x0, x1 = synth_pair(256, 256, 1)
+    t0 = time.perf_counter()
+    fo.film_forward(x0, x1, weights, fo.Options())
+    dt = time.perf_counter() - t0
+    ratio = (256 * 256) / (4 * 576 * 960)  # conv FLOPs are exactly proportional to padded pixels
+    return {
+        'value': round(ratio / dt, 6), 'unit': 'frames/s (1080p 2x2-tiled equivalent)', 'cores': ncores,
+        'kind': 'port',
+        'sample': f'one 256x256 pair, published film_net, {dt:.2f} s on {ncores} threads '
+                  f'(PyTorch-CPU oneDNN convs + numpy warp/resize restatement); scaled by the conv-FLOP ratio '
+                  f'{ratio:.5f} to a 1080p 2x2-tiled frame; the TF2 reference itself is not installable here',
+        'seconds': round(dt, 3),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED
+    from film_hip.torch_io import DeviceInterpolator
+
+    eng = FilmEngine(PUBLISHED, device=local_rank)
+    nblob = eng.packed_size()
+    weights = None
+    if rank == 0:
+        weights = W.make_synthetic_weights(PUBLISHED, seed=0)
+        eng.set_weights(weights)
+    if world > 1:
+        # one-time RCCL broadcast of the packed weight blob (137.7 MB) from rank 0
+        blob = torch.empty(nblob, dtype=torch.float32, device=dev)
+        if rank == 0:
+            eng.export_packed_device(blob.data_ptr(), nblob)
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize()
+        if rank != 0:
+            eng.import_packed_device(blob.data_ptr(), nblob)
+        del blob
+    if args.no_graph:
+        eng.set_option('graph', 0)
+
+    H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
+    x0n, x1n = synth_pair(H, Wd, 2 + rank)
+    x0 = torch.from_numpy(x0n).to(dev)
+    x1 = torch.from_numpy(x1n).to(dev)
+    it = DeviceInterpolator(eng, align=align, block_shape=block)
+
+    out = None
+    for _ in range(args.warmup):
+        out = it(x0, x1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = it(x0, x1)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out is not None and bool(torch.isfinite(out).all())
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel class: hipEvents around every launch, on the launch stream
+        eng.set_option('profile', 1)
+        it(x0, x1)
+        torch.cuda.synchronize()
+        prof = eng.profile()
+        eng.set_option('profile', 0)
+        if args.profile_out:
+            with open(args.profile_out, 'w') as f:
+                json.dump(prof, f)
+        cls = prof['classes']
+        conv = cls['conv_mfma']
+        npix = ntiles * tile_hw[0] * tile_hw[1]
+        alg_flops = CONV_FLOP_PER_PIXEL * npix
+        # conv_mfma launches carry all conv FLOPs except the Cin=3 first layer and the tiny 1x1 heads
+        conv_tflops = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
+        total_ms = sum(c['ms'] for c in cls.values())
+        roofline = {
+            'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)',
+            'achieved': round(conv_tflops, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+            'launches_per_step': conv['launches'],
+            'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
+            'class_ms_per_step': round(conv['ms'], 3),
+            'algorithmic_flops_per_step': conv['flops'],
+            'all_conv_flops_per_step': alg_flops,
+            'share_of_kernel_time': round(conv['ms'] / total_ms, 4),
+        }
+        extra = {}
+        if 'warp' in cls:
+            wgbs = cls['warp']['bytes'] / (cls['warp']['ms'] * 1e-3) / 1e9
+            extra['roofline_warp'] = {
+                'bound': 'hbm', 'kernel': 'warp_vec_kernel (bilinear gather)', 'achieved': round(wgbs, 1),
+                'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(wgbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                'launches_per_step': cls['warp']['launches'], 'class_ms_per_step': round(cls['warp']['ms'], 3),
+                'algorithmic_bytes_per_step': cls['warp']['bytes'],
+            }
+        extra['kernel_ms_per_step'] = {k: round(v['ms'], 3) for k, v in cls.items()}
+        value = world * args.steps / dt
+        result = {
+            'metric': 'interpolated frames/sec @1080p', 'value': round(value, 4), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: {Wd}x{H} pair, align {align}, block_shape {block} -> '
+                                   f'{ntiles} tile(s) of {tile_hw[1]}x{tile_hw[0]} in one batch, film_net published '
+                                   f'config, seeded synthetic weights, t=0.5',
+                       'frames_per_step_per_gpu': 1, 'parallelism': f'{world} independent GPU(s), weights RCCL-broadcast once',
+                       'graph': not args.no_graph},
+            'roofline': roofline,
+        }
+        result.update(extra)
+        if world == 1 and not args.no_cpu_baseline:
+            result['cpu_baseline'] = cpu_baseline(weights)
+        else:
+            result['cpu_baseline'] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,970 @@
+// film_engine.cpp -- C-ABI (include/film_hip.h), weight store/packer, planner and executor of the
+// MI355X FILM inference engine.
+//
+// The planner restates the *graph* of models/film_net/interpolator.py:89-207 as a static list of
+// kernel launches over one workspace arena for a given (B,H,W):
+//   image pyramids     util.py:23-45                -> pool ops on [2B,...,3] (both images in one batch)
+//   feature extractor  feature_extractor.py:163-193 -> conv ops writing straight into the cascaded slots
+//   flow estimator     pyramid_flow_estimator.py:125-163 -> both directions batched as 2B
+//   flow synthesis     util.py:106-117              -> reuses the estimator's v (identical arithmetic)
+//   warps + concat     interpolator.py:163-183      -> warp ops writing into the aligned pyramid
+//   fusion             fusion.py:103-140            -> NN-upsample folded into the 2x2 conv's gather
+// There is no CPU execution path here: plan-only handles (device = -1) can pack weights and describe
+// plans, every compute entry point needs a HIP device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/film_hip.h"
+#include "film_kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+enum OpKind { OP_CONV = 0, OP_CONV_C3, OP_CONV_PW, OP_POOL, OP_FLOW_UP, OP_FLOW_ADD, OP_WARP, OP_PACK_FLOW, OP_KINDS };
+const char* kKindName[OP_KINDS] = {"conv_mfma", "conv_c3", "conv_pw", "pool", "flow_up", "flow_add", "warp", "pack_flow"};
+
+struct Buffer {
+  std::string name;
+  int64_t off;  // floats from arena base
+  int N, H, W, C;      // all 0 for scratch regions (reinterpreted per use)
+  int64_t floats;      // extent
+  int64_t size() const { return floats; }
+};
+
+// A channel slice of (a batch range of) a workspace buffer, or of a scratch region.
+struct View {
+  int buf = -1;
+  int64_t off = 0;  // floats from arena base to the first element of the view
+  int stride = 0;   // floats per pixel
+  int C = 0;
+};
+
+struct SegDesc {
+  View v;
+  int boff = 0, bmod = 0, up = 0;
+};
+
+struct OpDesc {
+  int kind = 0;
+  std::string tag;
+  // conv
+  SegDesc seg[FILM_MAX_SEG];
+  int nseg = 0;
+  int ksize = 1, leaky = 0, Cout = 0, Ctot = 0, tile = 0;
+  int64_t w_off = 0, b_off = 0;
+  // generic views
+  View in, in2, out;
+  int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
+  float fscale = 1.f;
+  int64_t n = 0;
+  double flops = 0;  // algorithmic FLOPs (reference channel counts)
+  double bytes = 0;  // algorithmic bytes (read once + write once)
+};
+
+struct LayerPack {
+  std::string name;
+  int kh, kw, cin, cout;     // reference shape
+  std::vector<int> perm;     // internal input channel -> reference input channel, -1 = zero row
+  int64_t w_off = 0, b_off = 0;
+  int ctot() const { return (int)perm.size(); }
+};
+
+struct HostTensor {
+  std::vector<int64_t> dims;
+  std::vector<float> data;
+};
+
+struct Plan {
+  int B = 0, H = 0, W = 0;
+  std::vector<Buffer> bufs;
+  std::vector<OpDesc> ops;
+  int64_t arena_floats = 0;
+  float* arena = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  hipGraph_t graph = nullptr;
+  std::vector<hipEvent_t> ev;
+  uint64_t last_use = 0;
+  int find(const std::string& n) const {
+    for (size_t i = 0; i < bufs.size(); ++i)
+      if (bufs[i].name == n) return (int)i;
+    return -1;
+  }
+};
+
+}  // namespace
+
+struct film_handle {
+  int device = -1;
+  bool plan_only = true;
+  film_config cfg{};
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::map<std::string, HostTensor> host_w;
+  std::vector<LayerPack> layers;
+  std::map<std::string, int> layer_idx;
+  int64_t packed_floats = 0;
+  std::vector<float> packed_host;
+  float* packed_dev = nullptr;
+  bool finalized = false;
+  std::vector<std::unique_ptr<Plan>> plans;
+  Plan* last_plan = nullptr;
+  uint64_t tick = 0;
+  int opt_graph = 1, opt_profile = 0;
+  std::string profile_json;
+};
+
+namespace {
+
+int fail(film_t* h, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (h) h->err = buf; else g_create_error = buf;
+  return code;
+}
+
+#define HIPCHK(h, expr)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail(h, FILM_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Architecture helpers (mirror frame-interpolation_amd/film_hip/weights.py)
+// ---------------------------------------------------------------------------------------------
+std::vector<int> feature_channels(const film_config& c) {  // feature_extractor.py:186-193
+  std::vector<int> out;
+  for (int l = 0; l < c.pyramid_levels; ++l) {
+    int ch = 0;
+    for (int j = 0; j < c.sub_levels; ++j)
+      if (j <= l) ch += c.filters << j;
+    out.push_back(ch);
+  }
+  return out;
+}
+int slot_offset(const film_config& c, int j) {  // channel offset of sub-pyramid stage j in a feature level
+  int o = 0;
+  for (int k = 0; k < j; ++k) o += c.filters << k;
+  return o;
+}
+std::vector<int> fusion_filters(const film_config& c) {  // fusion.py:75-79
+  std::vector<int> out;
+  for (int i = 0; i < c.fusion_pyramid_levels - 1; ++i)
+    out.push_back(i < c.specialized_levels ? (c.filters << i) : (c.filters << c.specialized_levels));
+  return out;
+}
+std::string predictor_prefix(const film_config& c, int level) {  // pyramid_flow_estimator.py:109-123
+  if (level < c.specialized_levels) return "predict_flow/flow_predictor_" + std::to_string(level);
+  return "predict_flow/flow_predictor_shared";
+}
+int predictor_index(const film_config& c, int level) { return std::min(level, c.specialized_levels); }
+
+int validate_config(film_t* h, const film_config& c) {
+  if (c.pyramid_levels < 1 || c.pyramid_levels > 12) return fail(h, FILM_ERR_INVALID, "pyramid_levels out of range");
+  if (c.pyramid_levels < c.fusion_pyramid_levels || c.fusion_pyramid_levels < 2)
+    return fail(h, FILM_ERR_INVALID, "config.pyramid_levels must be greater than or equal to config.fusion_pyramid_levels.");
+  if (c.specialized_levels < 1 || c.specialized_levels > c.pyramid_levels || c.specialized_levels > FILM_MAX_SPECIALIZED)
+    return fail(h, FILM_ERR_INVALID, "specialized_levels out of range");
+  if (c.sub_levels < 1 || c.sub_levels > c.specialized_levels + 1)
+    return fail(h, FILM_ERR_INVALID, "sub_levels must be within [1, specialized_levels+1]");
+  if (c.filters <= 0 || c.filters % 32) return fail(h, FILM_ERR_INVALID, "filters must be a positive multiple of 32");
+  for (int i = 0; i <= c.specialized_levels; ++i) {
+    int nf = c.flow_filters[i];
+    if (nf <= 0 || nf % 32 || !(nf / 2 == 16 || (nf / 2) % 32 == 0))
+      return fail(h, FILM_ERR_INVALID, "flow_filters[%d]=%d unsupported (need 32 or a multiple of 64)", i, nf);
+    if (c.flow_convs[i] < 1) return fail(h, FILM_ERR_INVALID, "flow_convs[%d] must be >= 1", i);
+  }
+  return FILM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Layer table + packing
+// ---------------------------------------------------------------------------------------------
+std::vector<int> identity_perm(int n) {
+  std::vector<int> p(n);
+  for (int i = 0; i < n; ++i) p[i] = i;
+  return p;
+}
+// internal channel order of an aligned-pyramid level: [feat0 C | feat1 C | img0 3 | img1 3 | bflow 2 | fflow 2 | 0 x6]
+// reference order (interpolator.py:167-183):          [img0 3 | feat0 C | img1 3 | feat1 C | bflow 2 | fflow 2]
+std::vector<int> aligned_perm(int C) {
+  std::vector<int> p;
+  for (int c = 0; c < C; ++c) p.push_back(3 + c);
+  for (int c = 0; c < C; ++c) p.push_back(3 + C + 3 + c);
+  for (int j = 0; j < 3; ++j) p.push_back(j);
+  for (int j = 0; j < 3; ++j) p.push_back(3 + C + j);
+  for (int j = 0; j < 4; ++j) p.push_back(2 * (3 + C) + j);
+  for (int j = 0; j < 6; ++j) p.push_back(-1);
+  return p;
+}
+
+void build_layers(film_t* h) {
+  const film_config& c = h->cfg;
+  h->layers.clear();
+  h->layer_idx.clear();
+  auto add = [&](const std::string& name, int kh, int kw, int cin, int cout, std::vector<int> perm) {
+    LayerPack L;
+    L.name = name; L.kh = kh; L.kw = kw; L.cin = cin; L.cout = cout; L.perm = std::move(perm);
+    h->layer_idx[name] = (int)h->layers.size();
+    h->layers.push_back(std::move(L));
+  };
+  int cin = 3;
+  for (int i = 0; i < c.sub_levels; ++i) {
+    int k = c.filters << i;
+    add("feat_net/sub_extractor/cfeat_conv_" + std::to_string(2 * i), 3, 3, cin, k, identity_perm(cin));
+    add("feat_net/sub_extractor/cfeat_conv_" + std::to_string(2 * i + 1), 3, 3, k, k, identity_perm(k));
+    cin = k;
+  }
+  auto fc = feature_channels(c);
+  for (int p = 0; p <= c.specialized_levels; ++p) {
+    std::string prefix = predictor_prefix(c, p);
+    int ci = 2 * fc[std::min(p, c.pyramid_levels - 1)];
+    int nf = c.flow_filters[p], nconv = c.flow_convs[p];
+    for (int j = 0; j < nconv; ++j) {
+      add(prefix + "/conv_" + std::to_string(j), 3, 3, ci, nf, identity_perm(ci));
+      ci = nf;
+    }
+    add(prefix + "/conv_" + std::to_string(nconv), 1, 1, nf, nf / 2, identity_perm(nf));
+    add(prefix + "/conv_" + std::to_string(nconv + 1), 1, 1, nf / 2, 2, identity_perm(nf / 2));
+  }
+  auto ff = fusion_filters(c);
+  const int FL = c.fusion_pyramid_levels;
+  for (int i = 0; i < FL - 1; ++i) {
+    const int aligned_ref = 2 * (3 + fc[i]) + 4;
+    std::vector<int> p0;
+    int net_c;
+    if (i == FL - 2) { net_c = 2 * (3 + fc[FL - 1]) + 4; p0 = aligned_perm(fc[FL - 1]); }
+    else { net_c = ff[i + 1]; p0 = identity_perm(net_c); }
+    add("fusion/convs_" + std::to_string(i) + "_0", 2, 2, net_c, ff[i], p0);
+    std::vector<int> p1 = aligned_perm(fc[i]);
+    for (int j = 0; j < ff[i]; ++j) p1.push_back(aligned_ref + j);
+    add("fusion/convs_" + std::to_string(i) + "_1", 3, 3, aligned_ref + ff[i], ff[i], p1);
+    add("fusion/convs_" + std::to_string(i) + "_2", 3, 3, ff[i], ff[i], identity_perm(ff[i]));
+  }
+  add("fusion/output_conv", 1, 1, ff[0], 3, identity_perm(ff[0]));
+  int64_t off = 0;
+  for (auto& L : h->layers) {
+    L.w_off = off;
+    off += (int64_t)L.kh * L.kw * L.ctot() * L.cout;
+    off = (off + 3) & ~int64_t(3);
+    L.b_off = off;
+    off += L.cout;
+    off = (off + 3) & ~int64_t(3);
+  }
+  h->packed_floats = off;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Planner
+// ---------------------------------------------------------------------------------------------
+struct Planner {
+  film_t* h;
+  Plan* P;
+  int64_t cursor = 0;
+
+  bool bad = false;
+  std::string bad_msg;
+
+  int add_buffer(const std::string& name, int N, int H, int W, int C) {
+    Buffer b{name, cursor, N, H, W, C, (int64_t)N * H * W * C};
+    cursor += (b.floats + 63) & ~int64_t(63);  // 256-byte alignment
+    P->bufs.push_back(b);
+    return (int)P->bufs.size() - 1;
+  }
+  int add_scratch(const std::string& name, int64_t floats) {
+    Buffer b{name, cursor, 0, 0, 0, 0, std::max<int64_t>(floats, 64)};
+    cursor += (b.floats + 63) & ~int64_t(63);
+    P->bufs.push_back(b);
+    return (int)P->bufs.size() - 1;
+  }
+  // view of channels [coff, coff+C) of batches [batch0, ...) of a buffer
+  View view(int buf, int batch0, int coff, int C) const {
+    const Buffer& b = P->bufs[buf];
+    View v;
+    v.buf = buf;
+    v.off = b.off + (int64_t)batch0 * b.H * b.W * b.C + coff;
+    v.stride = b.C;
+    v.C = C;
+    return v;
+  }
+  // scratch view: reinterpret the start of a scratch buffer as [*][*][*][C]
+  View scratch(int buf, int C) const {
+    View v;
+    v.buf = buf; v.off = P->bufs[buf].off; v.stride = C; v.C = C;
+    return v;
+  }
+
+  static int choose_tile(int64_t M, int Cout) {
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (Cout / bn); };
+    if (Cout % 128 == 0) return blocks(128, 128) >= 256 ? TILE_128x128 : TILE_64x64;
+    if (Cout % 64 == 0) return blocks(256, 64) >= 256 ? TILE_256x64 : TILE_64x64;
+    return blocks(256, 32) >= 256 ? TILE_256x32 : TILE_128x32;
+  }
+
+  void conv(const std::string& tag, const std::string& layer, std::vector<SegDesc> segs, View out, int NB, int H,
+            int W, bool leaky) {
+    const LayerPack& L = h->layers[h->layer_idx.at(layer)];
+    OpDesc op;
+    op.kind = OP_CONV;
+    op.tag = tag + ":" + layer;
+    op.nseg = (int)segs.size();
+    int ctot = 0;
+    for (int i = 0; i < op.nseg; ++i) { op.seg[i] = segs[i]; ctot += segs[i].v.C; }
+    op.ksize = L.kh; op.leaky = leaky; op.Cout = L.cout; op.Ctot = ctot;
+    if (ctot != L.ctot() || out.C != L.cout || op.nseg > FILM_MAX_SEG) {
+      bad = true;
+      bad_msg = "planner: channel mismatch at " + op.tag;
+    }
+    op.w_off = L.w_off; op.b_off = L.b_off;
+    op.out = out; op.NB = NB; op.H = H; op.W = W;
+    const int64_t M = (int64_t)NB * H * W;
+    op.tile = choose_tile(M, L.cout);
+    op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
+    op.bytes = 4.0 * M * (L.cin + L.cout);
+    P->ops.push_back(op);
+  }
+  void conv_pw(const std::string& tag, const std::string& layer, View in, View out, int64_t M, bool leaky) {
+    const LayerPack& L = h->layers[h->layer_idx.at(layer)];
+    OpDesc op;
+    op.kind = OP_CONV_PW; op.tag = tag + ":" + layer;
+    op.in = in; op.out = out; op.n = M; op.leaky = leaky; op.Cout = L.cout; op.Ctot = L.cin;
+    op.w_off = L.w_off; op.b_off = L.b_off;
+    op.flops = 2.0 * M * L.cout * L.cin; op.bytes = 4.0 * M * (L.cin + L.cout);
+    P->ops.push_back(op);
+  }
+  void pool(const std::string& tag, View in, View out, int NB, int H, int W) {
+    OpDesc op;
+    op.kind = OP_POOL; op.tag = tag; op.in = in; op.out = out; op.NB = NB; op.H = H; op.W = W;
+    op.bytes = 4.0 * NB * H * W * in.C * 1.25;
+    P->ops.push_back(op);
+  }
+  void warp(const std::string& tag, View src, View flow, View dst, int NB, int H, int W, float fscale) {
+    OpDesc op;
+    op.kind = OP_WARP; op.tag = tag; op.in = src; op.in2 = flow; op.out = dst;
+    op.NB = NB; op.H = H; op.W = W; op.fscale = fscale;
+    op.bytes = 4.0 * NB * H * W * (2.0 * src.C + 2);  // read source once + flow, write once
+    P->ops.push_back(op);
+  }
+
+  int build(int B, int H, int W) {
+    const film_config& c = h->cfg;
+    const int L = c.pyramid_levels, FL = c.fusion_pyramid_levels;
+    const int N2 = 2 * B;
+    auto fc = feature_channels(c);
+    auto ff = fusion_filters(c);
+    auto HL = [&](int l) { return H >> l; };
+    auto WL = [&](int l) { return W >> l; };
+    P->B = B; P->H = H; P->W = W;
+
+    // ---- buffers ---------------------------------------------------------------------------
+    std::vector<int> img(L), feat(L), res(L), v(L), vup(L), warped(L), aligned(FL), fu_u(FL), fu_a(FL), fu_b(FL);
+    for (int l = 0; l < L; ++l) img[l] = add_buffer("img" + std::to_string(l), N2, HL(l), WL(l), 3);
+    for (int l = 0; l < L; ++l) feat[l] = add_buffer("feat" + std::to_string(l), N2, HL(l), WL(l), fc[l]);
+    // feature-extractor scratch: stage-j conv_2j output and pooled input, sized for the largest use
+    int64_t fx_sz = 0, fxp_sz = 0, fp_sz = 0;
+    for (int i = 0; i < L; ++i)
+      for (int j = 0; j < std::min(L - i, c.sub_levels); ++j) {
+        fx_sz = std::max<int64_t>(fx_sz, (int64_t)N2 * HL(i + j) * WL(i + j) * (c.filters << j));
+        if (j + 1 < std::min(L - i, c.sub_levels))
+          fxp_sz = std::max<int64_t>(fxp_sz, (int64_t)N2 * HL(i + j + 1) * WL(i + j + 1) * (c.filters << j));
+      }
+    const int fx_a = add_scratch("scratch_fx_a", fx_sz);
+    const int fx_p = add_scratch("scratch_fx_p", fxp_sz);
+    for (int l = 0; l < L; ++l) {
+      const int nf = c.flow_filters[predictor_index(c, l)];
+      fp_sz = std::max<int64_t>(fp_sz, (int64_t)N2 * HL(l) * WL(l) * nf);
+    }
+    int fp[3];
+    for (int k = 0; k < 3; ++k) fp[k] = add_scratch("scratch_fp_" + std::to_string(k), fp_sz);
+    for (int l = 0; l < L; ++l) res[l] = add_buffer("res" + std::to_string(l), N2, HL(l), WL(l), 2);
+    for (int l = 0; l < L - 1; ++l) {
+      vup[l] = add_buffer("vup" + std::to_string(l), N2, HL(l), WL(l), 2);
+      v[l] = add_buffer("v" + std::to_string(l), N2, HL(l), WL(l), 2);
+      warped[l] = add_buffer("warped" + std::to_string(l), N2, HL(l), WL(l), fc[l]);
+    }
+    v[L - 1] = res[L - 1];  // coarsest: the DC term is the flow itself (pyramid_flow_estimator.py:149-150)
+    for (int l = 0; l < FL; ++l) aligned[l] = add_buffer("aligned" + std::to_string(l), B, HL(l), WL(l), 2 * fc[l] + 16);
+    for (int i = 0; i < FL - 1; ++i) {
+      fu_u[i] = add_buffer("fusion_up" + std::to_string(i), B, HL(i), WL(i), ff[i]);
+      fu_a[i] = add_buffer("fusion_a" + std::to_string(i), B, HL(i), WL(i), ff[i]);
+      fu_b[i] = add_buffer("fusion_b" + std::to_string(i), B, HL(i), WL(i), ff[i]);
+    }
+    const int out = add_buffer("out", B, H, W, 3);
+    P->arena_floats = cursor;
+
+    // ---- image pyramids (util.py:23-45), both images as one batch of 2B ----------------------
+    for (int l = 0; l + 1 < L; ++l)
+      pool("image_pyramid_l" + std::to_string(l + 1), view(img[l], 0, 0, 3), view(img[l + 1], 0, 0, 3), N2, HL(l), WL(l));
+
+    // ---- cascaded feature extractor (feature_extractor.py:163-193) --------------------------------
+    for (int i = 0; i < L; ++i) {
+      const int n = std::min(L - i, c.sub_levels);
+      for (int j = 0; j < n; ++j) {
+        const int lv = i + j, k = c.filters << j;
+        const std::string tg = "feat_s" + std::to_string(i) + "_" + std::to_string(j);
+        const std::string w0 = "feat_net/sub_extractor/cfeat_conv_" + std::to_string(2 * j);
+        const std::string w1 = "feat_net/sub_extractor/cfeat_conv_" + std::to_string(2 * j + 1);
+        View tmp = scratch(fx_a, k);
+        if (j == 0) {
+          const LayerPack& Lp = h->layers[h->layer_idx.at(w0)];
+          OpDesc op;
+          op.kind = OP_CONV_C3; op.tag = tg + ":" + w0;
+          op.in = view(img[i], 0, 0, 3); op.out = tmp; op.NB = N2; op.H = HL(lv); op.W = WL(lv);
+          op.Cout = k; op.leaky = 1; op.w_off = Lp.w_off; op.b_off = Lp.b_off;
+          op.flops = 2.0 * N2 * HL(lv) * WL(lv) * k * 27; op.bytes = 4.0 * N2 * HL(lv) * WL(lv) * (3 + k);
+          P->ops.push_back(op);
+        } else {
+          SegDesc s; s.v = scratch(fx_p, k >> 1);
+          conv(tg, w0, {s}, tmp, N2, HL(lv), WL(lv), true);
+        }
+        SegDesc s1; s1.v = tmp;
+        View dst = view(feat[lv], 0, slot_offset(c, j), k);
+        conv(tg, w1, {s1}, dst, N2, HL(lv), WL(lv), true);
+        if (j < n - 1) pool(tg + ":pool", dst, scratch(fx_p, k), N2, HL(lv), WL(lv));
+      }
+    }
+
+    // ---- bidirectional coarse-to-fine flow (pyramid_flow_estimator.py:125-163) ---------------------
+    // batch n = d*B + b: d = 0 forward (a = image 0, b = image 1), d = 1 backward.
+    for (int l = L - 1; l >= 0; --l) {
+      const std::string tg = "flow_l" + std::to_string(l);
+      const int pi = predictor_index(c, l);
+      const int nf = c.flow_filters[pi], nconv = c.flow_convs[pi];
+      const std::string prefix = predictor_prefix(c, l);
+      const int Hl = HL(l), Wl = WL(l);
+      SegDesc sa; sa.v = view(feat[l], 0, 0, fc[l]);
+      SegDesc sb;
+      if (l == L - 1) {
+        sb.v = view(feat[l], 0, 0, fc[l]); sb.boff = B; sb.bmod = N2;  // the other image's features
+      } else {
+        OpDesc up;
+        up.kind = OP_FLOW_UP; up.tag = tg + ":resize2x";
+        up.in = view(v[l + 1], 0, 0, 2); up.out = view(vup[l], 0, 0, 2);
+        up.NB = N2; up.H = HL(l + 1); up.W = WL(l + 1);
+        up.bytes = 4.0 * N2 * Hl * Wl * 2 * 1.25;
+        P->ops.push_back(up);
+        for (int d = 0; d < 2; ++d)  // warp the OTHER image's features with this direction's flow
+          warp(tg + ":warp_d" + std::to_string(d), view(feat[l], (1 - d) * B, 0, fc[l]), view(vup[l], d * B, 0, 2),
+               view(warped[l], d * B, 0, fc[l]), B, Hl, Wl, 1.f);
+        sb.v = view(warped[l], 0, 0, fc[l]);
+      }
+      View cur = scratch(fp[0], nf);
+      conv(tg, prefix + "/conv_0", {sa, sb}, cur, N2, Hl, Wl, true);
+      int which = 0;
+      for (int j = 1; j < nconv; ++j) {
+        View nxt = scratch(fp[which ^ 1], nf);
+        SegDesc s; s.v = cur;
+        conv(tg, prefix + "/conv_" + std::to_string(j), {s}, nxt, N2, Hl, Wl, true);
+        cur = nxt; which ^= 1;
+      }
+      View hid = scratch(fp[2], nf / 2);
+      const std::string l3 = prefix + "/conv_" + std::to_string(nconv), l4 = prefix + "/conv_" + std::to_string(nconv + 1);
+      if ((nf / 2) % 32 == 0) { SegDesc s; s.v = cur; conv(tg, l3, {s}, hid, N2, Hl, Wl, true); }
+      else conv_pw(tg, l3, cur, hid, (int64_t)N2 * Hl * Wl, true);
+      conv_pw(tg, l4, hid, view(res[l], 0, 0, 2), (int64_t)N2 * Hl * Wl, false);
+      if (l < L - 1) {
+        OpDesc ad;
+        ad.kind = OP_FLOW_ADD; ad.tag = tg + ":v=res+up";
+        ad.in = view(res[l], 0, 0, 2); ad.in2 = view(vup[l], 0, 0, 2); ad.out = view(v[l], 0, 0, 2);
+        ad.n = (int64_t)N2 * Hl * Wl * 2; ad.bytes = 4.0 * ad.n * 3;
+        P->ops.push_back(ad);
+      }
+    }
+
+    // ---- warp to t = 0.5 and build the aligned pyramid (interpolator.py:153-183) ------------------
+    // util.flow_pyramid_synthesis recomputes exactly the v sequence above, so v is reused.
+    // image s is sampled with the flow of the opposite direction: image 0 <- backward flow (d=1).
+    for (int l = 0; l < FL; ++l) {
+      const std::string tg = "align_l" + std::to_string(l);
+      for (int s = 0; s < 2; ++s) {
+        View fl = view(v[l], (1 - s) * B, 0, 2);
+        warp(tg + ":warp_feat" + std::to_string(s), view(feat[l], s * B, 0, fc[l]), fl,
+             view(aligned[l], 0, s * fc[l], fc[l]), B, HL(l), WL(l), 0.5f);
+        warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
+             view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f);
+      }
+      OpDesc pk;
+      pk.kind = OP_PACK_FLOW; pk.tag = tg + ":flows";
+      pk.in = view(v[l], B, 0, 2);   // backward flow (d = 1)
+      pk.in2 = view(v[l], 0, 0, 2);  // forward flow  (d = 0)
+      pk.out = view(aligned[l], 0, 2 * fc[l] + 6, 10);
+      pk.n = (int64_t)B * HL(l) * WL(l); pk.bytes = 4.0 * pk.n * 14;
+      P->ops.push_back(pk);
+    }
+
+    // ---- fusion decoder (fusion.py:103-140) ---------------------------------------------------------
+    View net = view(aligned[FL - 1], 0, 0, 2 * fc[FL - 1] + 16);
+    for (int i = FL - 2; i >= 0; --i) {
+      const std::string tg = "fusion_l" + std::to_string(i);
+      const std::string base = "fusion/convs_" + std::to_string(i);
+      SegDesc su; su.v = net; su.up = 1;
+      conv(tg, base + "_0", {su}, view(fu_u[i], 0, 0, ff[i]), B, HL(i), WL(i), false);
+      SegDesc s0; s0.v = view(aligned[i], 0, 0, 2 * fc[i] + 16);
+      SegDesc s1; s1.v = view(fu_u[i], 0, 0, ff[i]);
+      conv(tg, base + "_1", {s0, s1}, view(fu_a[i], 0, 0, ff[i]), B, HL(i), WL(i), true);
+      SegDesc s2; s2.v = view(fu_a[i], 0, 0, ff[i]);
+      conv(tg, base + "_2", {s2}, view(fu_b[i], 0, 0, ff[i]), B, HL(i), WL(i), true);
+      net = view(fu_b[i], 0, 0, ff[i]);
+    }
+    conv_pw("fusion_out", "fusion/output_conv", net, view(out, 0, 0, 3), (int64_t)B * H * W, false);
+    if (bad) return fail(h, FILM_ERR_INVALID, "%s", bad_msg.c_str());
+    return FILM_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// Executor
+// ---------------------------------------------------------------------------------------------
+inline const float* cptr(const float* base, const View& v) { return base + v.off; }
+inline float* mptr(float* base, const View& v) { return base + v.off; }
+
+hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream_t s) {
+  switch (op.kind) {
+    case OP_CONV: {
+      ConvParams p{};
+      p.nseg = op.nseg;
+      for (int i = 0; i < op.nseg; ++i) {
+        p.seg[i].ptr = cptr(arena, op.seg[i].v);
+        p.seg[i].stride = op.seg[i].v.stride;
+        p.seg[i].C = op.seg[i].v.C;
+        p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
+      }
+      p.ksize = op.ksize; p.w = wts + op.w_off; p.bias = wts + op.b_off;
+      p.out = mptr(arena, op.out); p.ostride = op.out.stride;
+      p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
+      p.M = op.NB * op.H * op.W;
+      return film_launch_conv(p, op.tile, s);
+    }
+    case OP_CONV_C3: {
+      ConvC3Params p{};
+      p.in = cptr(arena, op.in); p.w = wts + op.w_off; p.bias = wts + op.b_off;
+      p.out = mptr(arena, op.out); p.ostride = op.out.stride;
+      p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.leaky = op.leaky;
+      return film_launch_conv_c3(p, s);
+    }
+    case OP_CONV_PW: {
+      ConvPwParams p{};
+      p.in = cptr(arena, op.in); p.istride = op.in.stride; p.Cin = op.Ctot;
+      p.w = wts + op.w_off; p.bias = wts + op.b_off;
+      p.out = mptr(arena, op.out); p.ostride = op.out.stride; p.Cout = op.Cout; p.leaky = op.leaky;
+      p.M = (int)op.n;
+      return film_launch_conv_pw(p, s);
+    }
+    case OP_POOL: {
+      PoolParams p{};
+      p.in = cptr(arena, op.in); p.istride = op.in.stride; p.out = mptr(arena, op.out); p.ostride = op.out.stride;
+      p.C = op.in.C; p.NB = op.NB; p.H = op.H; p.W = op.W;
+      return film_launch_pool(p, s);
+    }
+    case OP_FLOW_UP: {
+      FlowUpParams p{};
+      p.in = cptr(arena, op.in); p.out = mptr(arena, op.out); p.NB = op.NB; p.h = op.H; p.w = op.W;
+      return film_launch_flow_up(p, s);
+    }
+    case OP_FLOW_ADD: {
+      FlowAddParams p{};
+      p.a = cptr(arena, op.in); p.b = cptr(arena, op.in2); p.out = mptr(arena, op.out); p.n = op.n;
+      return film_launch_flow_add(p, s);
+    }
+    case OP_WARP: {
+      WarpParams p{};
+      p.src = cptr(arena, op.in); p.sstride = op.in.stride; p.C = op.in.C;
+      p.flow = cptr(arena, op.in2); p.fscale = op.fscale;
+      p.dst = mptr(arena, op.out); p.dstride = op.out.stride;
+      p.NB = op.NB; p.H = op.H; p.W = op.W;
+      return film_launch_warp(p, s);
+    }
+    case OP_PACK_FLOW: {
+      PackFlowParams p{};
+      p.bflow = cptr(arena, op.in); p.fflow = cptr(arena, op.in2);
+      p.dst = mptr(arena, op.out); p.dstride = op.out.stride; p.npix = op.n;
+      return film_launch_pack_flow(p, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
+void free_plan(Plan* p) {
+  if (!p) return;
+  if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  for (auto e : p->ev) (void)hipEventDestroy(e);
+  if (p->arena) (void)hipFree(p->arena);
+}
+
+int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
+  const int div = 1 << (h->cfg.pyramid_levels - 1);
+  if (B < 1 || H < 1 || W < 1) return fail(h, FILM_ERR_INVALID, "B, H, W must be positive");
+  if (H % div || W % div)
+    return fail(h, FILM_ERR_INVALID, "input height and width (%d x %d) must be divisible by %d = 2^(pyramid_levels-1); "
+                "pad first (Interpolator align)", H, W, div);
+  // tfa dense_image_warp needs a >= 2x2 grid at every warped level
+  const int wl = std::max(h->cfg.pyramid_levels - 2, h->cfg.fusion_pyramid_levels - 1);
+  if ((H >> wl) < 2 || (W >> wl) < 2)
+    return fail(h, FILM_ERR_INVALID, "input %d x %d too small: warped pyramid level %d would be smaller than 2x2", H, W, wl);
+  if ((int64_t)2 * B * H * W >= (int64_t)1 << 31) return fail(h, FILM_ERR_INVALID, "batch too large (2*B*H*W must fit int32)");
+  for (auto& p : h->plans)
+    if (p->B == B && p->H == H && p->W == W && (!need_device || p->arena)) { *out = p.get(); p->last_use = ++h->tick; return FILM_OK; }
+  std::unique_ptr<Plan> P(new Plan);
+  Planner pl{h, P.get()};
+  int rc = pl.build(B, H, W);
+  if (rc) return rc;
+  if (need_device) {
+    // keep at most 3 device plans alive (workspaces are GBs at 1080p tiles)
+    size_t alive = 0;
+    for (auto& p : h->plans) alive += p->arena != nullptr;
+    while (alive >= 3) {
+      size_t victim = h->plans.size();
+      for (size_t i = 0; i < h->plans.size(); ++i)
+        if (h->plans[i]->arena && (victim == h->plans.size() || h->plans[i]->last_use < h->plans[victim]->last_use)) victim = i;
+      if (victim == h->plans.size()) break;
+      if (h->last_plan == h->plans[victim].get()) h->last_plan = nullptr;
+      free_plan(h->plans[victim].get());
+      h->plans.erase(h->plans.begin() + victim);
+      --alive;
+    }
+    hipError_t e = hipMalloc(&P->arena, (size_t)P->arena_floats * sizeof(float));
+    if (e != hipSuccess) {
+      P->arena = nullptr;
+      return fail(h, FILM_ERR_NOMEM, "workspace hipMalloc of %.1f MB failed: %s", P->arena_floats * 4e-6, hipGetErrorString(e));
+    }
+    HIPCHK(h, hipMemsetAsync(P->arena, 0, (size_t)P->arena_floats * sizeof(float), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  P->last_use = ++h->tick;
+  *out = P.get();
+  h->plans.push_back(std::move(P));
+  return FILM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// JSON helpers
+// ---------------------------------------------------------------------------------------------
+void json_view(std::ostringstream& o, const char* key, const View& v, const Plan& P) {
+  o << "\"" << key << "\":{\"buf\":\"" << (v.buf >= 0 ? P.bufs[v.buf].name : std::string("")) << "\",\"off\":" << v.off
+    << ",\"stride\":" << v.stride << ",\"C\":" << v.C << "}";
+}
+
+std::string plan_json(film_t* h, const Plan& P) {
+  std::ostringstream o;
+  o << "{\"B\":" << P.B << ",\"H\":" << P.H << ",\"W\":" << P.W << ",\"arena_floats\":" << P.arena_floats
+    << ",\"packed_floats\":" << h->packed_floats << ",\"buffers\":[";
+  for (size_t i = 0; i < P.bufs.size(); ++i) {
+    const Buffer& b = P.bufs[i];
+    o << (i ? "," : "") << "{\"name\":\"" << b.name << "\",\"off\":" << b.off << ",\"N\":" << b.N << ",\"H\":" << b.H
+      << ",\"W\":" << b.W << ",\"C\":" << b.C << ",\"floats\":" << b.floats << "}";
+  }
+  o << "],\"layers\":[";
+  for (size_t i = 0; i < h->layers.size(); ++i) {
+    const LayerPack& L = h->layers[i];
+    o << (i ? "," : "") << "{\"name\":\"" << L.name << "\",\"kh\":" << L.kh << ",\"kw\":" << L.kw << ",\"cin\":" << L.cin
+      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << "}";
+  }
+  o << "],\"ops\":[";
+  for (size_t i = 0; i < P.ops.size(); ++i) {
+    const OpDesc& op = P.ops[i];
+    o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
+      << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
+      << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
+      << ",\"b_off\":" << op.b_off << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
+      << ",\"bytes\":" << op.bytes << ",";
+    json_view(o, "in", op.in, P); o << ",";
+    json_view(o, "in2", op.in2, P); o << ",";
+    json_view(o, "out", op.out, P);
+    o << ",\"segs\":[";
+    for (int k = 0; k < op.nseg; ++k) {
+      o << (k ? "," : "") << "{";
+      json_view(o, "v", op.seg[k].v, P);
+      o << ",\"boff\":" << op.seg[k].boff << ",\"bmod\":" << op.seg[k].bmod << ",\"up\":" << op.seg[k].up << "}";
+    }
+    o << "]}";
+  }
+  o << "]}";
+  return o.str();
+}
+
+int copy_out_string(film_t* h, const std::string& s, char* buf, int64_t cap, int64_t* needed) {
+  if (needed) *needed = (int64_t)s.size() + 1;
+  if (!buf || cap < (int64_t)s.size() + 1) {
+    if (!buf && needed) return FILM_OK;  // size query
+    return fail(h, FILM_ERR_INVALID, "buffer too small: need %lld bytes", (long long)s.size() + 1);
+  }
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return FILM_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C-ABI
+// =============================================================================================
+extern "C" {
+
+const char* film_version(void) { return "gfx950;film_hip r1"; }
+
+int film_default_config(film_config* cfg) {
+  if (!cfg) return FILM_ERR_INVALID;
+  memset(cfg, 0, sizeof *cfg);
+  cfg->pyramid_levels = 7; cfg->fusion_pyramid_levels = 5; cfg->specialized_levels = 3; cfg->sub_levels = 4;
+  cfg->filters = 64;
+  const int fcv[4] = {3, 3, 3, 3}, ffl[4] = {32, 64, 128, 256};
+  for (int i = 0; i < 4; ++i) { cfg->flow_convs[i] = fcv[i]; cfg->flow_filters[i] = ffl[i]; }
+  return FILM_OK;
+}
+
+int film_create(film_t** out, int device, const film_config* cfg) {
+  if (!out) return fail(nullptr, FILM_ERR_INVALID, "out is NULL");
+  *out = nullptr;
+  std::unique_ptr<film_handle> h(new film_handle);
+  if (cfg) h->cfg = *cfg; else film_default_config(&h->cfg);
+  int rc = validate_config(h.get(), h->cfg);
+  if (rc) { g_create_error = h->err; return rc; }
+  h->device = device;
+  h->plan_only = device < 0;
+  if (!h->plan_only) {
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+      return fail(nullptr, FILM_ERR_NO_DEVICE, "no HIP device available (%s); libfilm_hip has no CPU fallback",
+                  e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    if (device >= ndev) return fail(nullptr, FILM_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+    if (hipSetDevice(device) != hipSuccess) return fail(nullptr, FILM_ERR_HIP, "hipSetDevice(%d) failed", device);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+      return fail(nullptr, FILM_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+      return fail(nullptr, FILM_ERR_HIP, "hipStreamCreate failed");
+  }
+  build_layers(h.get());
+  *out = h.release();
+  return FILM_OK;
+}
+
+void film_destroy(film_t* h) {
+  if (!h) return;
+  if (!h->plan_only) {
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+  }
+  for (auto& p : h->plans) free_plan(p.get());
+  if (h->packed_dev) (void)hipFree(h->packed_dev);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+const char* film_last_error(const film_t* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int film_set_weight(film_t* h, const char* name, const float* data, const int64_t* dims, int ndim) {
+  if (!h || !name || !data || !dims || ndim < 1 || ndim > 4) return fail(h, FILM_ERR_INVALID, "bad argument");
+  std::string nm(name);
+  const size_t slash = nm.rfind('/');
+  if (slash == std::string::npos) return fail(h, FILM_ERR_NOTFOUND, "unknown weight '%s'", name);
+  const std::string layer = nm.substr(0, slash), kind = nm.substr(slash + 1);
+  auto it = h->layer_idx.find(layer);
+  if (it == h->layer_idx.end() || (kind != "kernel" && kind != "bias")) return fail(h, FILM_ERR_NOTFOUND, "unknown weight '%s'", name);
+  const LayerPack& L = h->layers[it->second];
+  int64_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= dims[i];
+  if (kind == "kernel") {
+    if (ndim != 4 || dims[0] != L.kh || dims[1] != L.kw || dims[2] != L.cin || dims[3] != L.cout)
+      return fail(h, FILM_ERR_INVALID, "%s: expected HWIO [%d,%d,%d,%d]", name, L.kh, L.kw, L.cin, L.cout);
+  } else if (ndim != 1 || dims[0] != L.cout) {
+    return fail(h, FILM_ERR_INVALID, "%s: expected [%d]", name, L.cout);
+  }
+  HostTensor t;
+  t.dims.assign(dims, dims + ndim);
+  t.data.assign(data, data + n);
+  h->host_w[nm] = std::move(t);
+  h->finalized = false;
+  return FILM_OK;
+}
+
+static int upload_packed(film_t* h) {
+  if (h->plan_only) return FILM_OK;
+  HIPCHK(h, hipSetDevice(h->device));
+  if (!h->packed_dev) HIPCHK(h, hipMalloc(&h->packed_dev, (size_t)h->packed_floats * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->packed_dev, h->packed_host.data(), (size_t)h->packed_floats * sizeof(float), hipMemcpyHostToDevice));
+  return FILM_OK;
+}
+
+int film_finalize(film_t* h) {
+  if (!h) return FILM_ERR_INVALID;
+  h->packed_host.assign((size_t)h->packed_floats, 0.f);
+  for (const LayerPack& L : h->layers) {
+    auto kw = h->host_w.find(L.name + "/kernel"), bw = h->host_w.find(L.name + "/bias");
+    if (kw == h->host_w.end() || bw == h->host_w.end()) return fail(h, FILM_ERR_STATE, "missing weight '%s'", L.name.c_str());
+    const float* src = kw->second.data.data();
+    float* dst = h->packed_host.data() + L.w_off;
+    const int ct = L.ctot();
+    for (int tap = 0; tap < L.kh * L.kw; ++tap)
+      for (int ci = 0; ci < ct; ++ci) {
+        const int ref = L.perm[ci];
+        if (ref < 0) continue;  // zero row (padding channel)
+        memcpy(dst + ((size_t)tap * ct + ci) * L.cout, src + ((size_t)tap * L.cin + ref) * L.cout, sizeof(float) * L.cout);
+      }
+    memcpy(h->packed_host.data() + L.b_off, bw->second.data.data(), sizeof(float) * L.cout);
+  }
+  int rc = upload_packed(h);
+  if (rc) return rc;
+  h->finalized = true;
+  return FILM_OK;
+}
+
+int film_packed_size(film_t* h, int64_t* n) {
+  if (!h || !n) return FILM_ERR_INVALID;
+  *n = h->packed_floats;
+  return FILM_OK;
+}
+
+int film_export_packed(film_t* h, float* dst, int64_t cap, int mem_kind) {
+  if (!h || !dst) return FILM_ERR_INVALID;
+  if (!h->finalized) return fail(h, FILM_ERR_STATE, "film_finalize has not been called");
+  if (cap < h->packed_floats) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)h->packed_floats);
+  if (mem_kind == FILM_MEM_HOST) { memcpy(dst, h->packed_host.data(), (size_t)h->packed_floats * sizeof(float)); return FILM_OK; }
+  if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle has no device");
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipMemcpy(dst, h->packed_dev, (size_t)h->packed_floats * sizeof(float), hipMemcpyDeviceToDevice));
+  return FILM_OK;
+}
+
+int film_import_packed(film_t* h, const float* src, int64_t n, int mem_kind) {
+  if (!h || !src) return FILM_ERR_INVALID;
+  if (n != h->packed_floats) return fail(h, FILM_ERR_INVALID, "blob has %lld floats, expected %lld", (long long)n, (long long)h->packed_floats);
+  h->packed_host.resize((size_t)n);
+  if (mem_kind == FILM_MEM_HOST) {
+    memcpy(h->packed_host.data(), src, (size_t)n * sizeof(float));
+  } else {
+    if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle has no device");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(h->packed_host.data(), src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  int rc = upload_packed(h);
+  if (rc) return rc;
+  h->finalized = true;
+  return FILM_OK;
+}
+
+int film_set_option(film_t* h, const char* key, int64_t value) {
+  if (!h || !key) return FILM_ERR_INVALID;
+  if (!strcmp(key, "graph")) h->opt_graph = value != 0;
+  else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
+  else return fail(h, FILM_ERR_NOTFOUND, "unknown option '%s'", key);
+  return FILM_OK;
+}
+
+int film_plan_json(film_t* h, int B, int H, int W, char* buf, int64_t cap, int64_t* needed) {
+  if (!h) return FILM_ERR_INVALID;
+  Plan* P = nullptr;
+  int rc = get_plan(h, B, H, W, false, &P);
+  if (rc) return rc;
+  return copy_out_string(h, plan_json(h, *P), buf, cap, needed);
+}
+
+int film_profile_json(film_t* h, char* buf, int64_t cap, int64_t* needed) {
+  if (!h) return FILM_ERR_INVALID;
+  if (h->profile_json.empty()) return fail(h, FILM_ERR_STATE, "no profiled forward yet (film_set_option(\"profile\", 1))");
+  return copy_out_string(h, h->profile_json, buf, cap, needed);
+}
+
+int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream) {
+  if (!h || !x0 || !x1 || !out) return fail(h, FILM_ERR_INVALID, "NULL argument");
+  if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle: film_forward needs a HIP device (no CPU fallback)");
+  if (!h->finalized) return fail(h, FILM_ERR_STATE, "film_finalize has not been called");
+  if (mem_kind != FILM_MEM_HOST && mem_kind != FILM_MEM_DEVICE) return fail(h, FILM_ERR_INVALID, "bad mem_kind");
+  HIPCHK(h, hipSetDevice(h->device));
+  Plan* P = nullptr;
+  int rc = get_plan(h, B, H, W, true, &P);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  const size_t in_bytes = (size_t)B * H * W * 3 * sizeof(float);
+  const hipMemcpyKind kin = mem_kind == FILM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const hipMemcpyKind kout = mem_kind == FILM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  const Buffer& img0 = P->bufs[P->find("img0")];
+  const Buffer& ob = P->bufs[P->find("out")];
+  HIPCHK(h, hipMemcpyAsync(P->arena + img0.off, x0, in_bytes, kin, s));
+  HIPCHK(h, hipMemcpyAsync(P->arena + img0.off + (int64_t)B * H * W * 3, x1, in_bytes, kin, s));
+
+  if (h->opt_profile) {
+    const size_t n = P->ops.size();
+    while (P->ev.size() < n + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); P->ev.push_back(e); }
+    HIPCHK(h, hipEventRecord(P->ev[0], s));
+    for (size_t i = 0; i < n; ++i) {
+      HIPCHK(h, launch_op(P->ops[i], P->arena, h->packed_dev, s));
+      HIPCHK(h, hipEventRecord(P->ev[i + 1], s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    struct Acc { int launches = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Acc> cls;
+    std::ostringstream ops;
+    for (size_t i = 0; i < n; ++i) {
+      float ms = 0;
+      HIPCHK(h, hipEventElapsedTime(&ms, P->ev[i], P->ev[i + 1]));
+      Acc& a = cls[kKindName[P->ops[i].kind]];
+      a.launches++; a.ms += ms; a.flops += P->ops[i].flops; a.bytes += P->ops[i].bytes;
+      ops << (i ? "," : "") << "{\"tag\":\"" << P->ops[i].tag << "\",\"kind\":\"" << kKindName[P->ops[i].kind] << "\",\"ms\":" << ms
+          << ",\"flops\":" << P->ops[i].flops << ",\"bytes\":" << P->ops[i].bytes << ",\"tile\":" << P->ops[i].tile << "}";
+    }
+    std::ostringstream o;
+    o << "{\"B\":" << B << ",\"H\":" << H << ",\"W\":" << W << ",\"classes\":{";
+    bool first = true;
+    for (auto& kv : cls) {
+      o << (first ? "" : ",") << "\"" << kv.first << "\":{\"launches\":" << kv.second.launches << ",\"ms\":" << kv.second.ms
+        << ",\"flops\":" << kv.second.flops << ",\"bytes\":" << kv.second.bytes << "}";
+      first = false;
+    }
+    o << "},\"ops\":[" << ops.str() << "]}";
+    h->profile_json = o.str();
+  } else if (h->opt_graph) {
+    if (!P->graph_exec) {
+      // capture on the handle's own stream, replay on whichever stream the caller wants
+      HIPCHK(h, hipStreamSynchronize(s));
+      HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+      hipError_t le = hipSuccess;
+      for (const OpDesc& op : P->ops) { le = launch_op(op, P->arena, h->packed_dev, h->stream); if (le != hipSuccess) break; }
+      hipError_t ce = hipStreamEndCapture(h->stream, &P->graph);
+      if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed during capture: %s", hipGetErrorString(le));
+      HIPCHK(h, ce);
+      HIPCHK(h, hipGraphInstantiate(&P->graph_exec, P->graph, nullptr, nullptr, 0));
+    }
+    HIPCHK(h, hipGraphLaunch(P->graph_exec, s));
+  } else {
+    for (const OpDesc& op : P->ops) HIPCHK(h, launch_op(op, P->arena, h->packed_dev, s));
+  }
+  HIPCHK(h, hipMemcpyAsync(out, P->arena + ob.off, in_bytes, kout, s));
+  if (mem_kind == FILM_MEM_HOST) HIPCHK(h, hipStreamSynchronize(s));
+  h->last_plan = P;
+  return FILM_OK;
+}
+
+int film_get_tap(film_t* h, const char* name, float* dst, int64_t cap, int64_t dims[4]) {
+  if (!h || !name) return FILM_ERR_INVALID;
+  if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle has no device");
+  Plan* P = h->last_plan;
+  if (!P || !P->arena) return fail(h, FILM_ERR_STATE, "no forward has run yet");
+  const int bi = P->find(name);
+  if (bi < 0) return fail(h, FILM_ERR_NOTFOUND, "unknown tap '%s'", name);
+  const Buffer& b = P->bufs[bi];
+  if (dims) { dims[0] = b.N; dims[1] = b.H; dims[2] = b.W; dims[3] = b.C; }
+  if (!dst) return FILM_OK;  // shape query
+  if (cap < b.size()) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)b.size());
+  HIPCHK(h, hipSetDevice(h->device));
+  HIPCHK(h, hipDeviceSynchronize());
+  HIPCHK(h, hipMemcpy(dst, P->arena + b.off, (size_t)b.size() * sizeof(float), hipMemcpyDeviceToHost));
+  return FILM_OK;
+}
+
+}  // extern "C"

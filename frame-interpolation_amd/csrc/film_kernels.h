@@ -1,0 +1,134 @@
+// film_kernels.h -- parameter blocks and launchers of the gfx950 kernels behind libfilm_hip.so.
+//
+// Every activation is a pixel-major ("NHWC") float32 buffer [N][H][W][stride]; a kernel reads
+// or writes a *channel slice* of such a buffer (pointer pre-offset by the first channel,
+// `stride` = floats per pixel of the underlying buffer).  That is how every tf.concat of the
+// reference (feature_extractor.py:191, pyramid_flow_estimator.py:95, interpolator.py:167-183,
+// fusion.py:136) disappears: producers write straight into their slice of the consumer's input.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FILM_MAX_SEG 4
+#define FILM_BK 16  // channels per K-step of the implicit GEMM; every concat segment is a multiple
+
+// One K-segment of a (virtually concatenated) convolution input.
+struct ConvSeg {
+  const float* ptr;  // [NBs][Hs][Ws][stride], first channel of the segment
+  int stride;        // floats per pixel
+  int C;             // channels in the segment, multiple of FILM_BK
+  int boff, bmod;    // batch remap: b' = b + boff; if (b' >= bmod) b' -= bmod   (bmod = 0: none)
+  int up;            // 1: source is (H/2, W/2); nearest-neighbour x2 on read (fusion.py:133-134)
+};
+
+// Conv2D(padding='same', stride 1) [+ bias] [+ leaky_relu(0.2)] as implicit GEMM:
+//   M = NB*H*W output pixels, N = Cout, K = ksize^2 * Ctot, K ordered (tap, segment, channel).
+struct ConvParams {
+  ConvSeg seg[FILM_MAX_SEG];
+  int nseg;
+  int ksize;          // 1, 2, 3; TF 'same': pad_before = (ksize-1)/2, rest after
+  const float* w;     // packed [ksize*ksize][Ctot][Cout]
+  const float* bias;  // [Cout]
+  float* out;         // [NB][H][W][ostride], first output channel
+  int ostride;
+  int NB, H, W;
+  int Cout, Ctot;
+  int leaky;
+  int M;
+};
+
+// First layer: Conv2D 3x3 on the 3-channel image (feature_extractor.py:119-120, cfeat_conv_0).
+struct ConvC3Params {
+  const float* in;    // [NB][H][W][3]
+  const float* w;     // [27][Cout]
+  const float* bias;
+  float* out;
+  int ostride;
+  int NB, H, W, Cout;
+  int leaky;
+};
+
+// 1x1 convolution with a tiny output width (Cout <= 16): flow heads and the RGB head.
+struct ConvPwParams {
+  const float* in;
+  int istride;
+  int Cin;            // multiple of 4
+  const float* w;     // [Cin][Cout]
+  const float* bias;
+  float* out;
+  int ostride;
+  int Cout;
+  int leaky;
+  int M;              // pixels
+};
+
+// AveragePooling2D(2, 2, 'valid') on a channel slice (util.py:39-40, feature_extractor.py:138-139).
+struct PoolParams {
+  const float* in;
+  int istride;
+  float* out;
+  int ostride;
+  int C;
+  int NB, H, W;       // INPUT spatial dims (even)
+};
+
+// tf.image.resize(2*v, 2x) bilinear, half-pixel centres (pyramid_flow_estimator.py:155).
+struct FlowUpParams {
+  const float* in;    // [NB][h][w][2]
+  float* out;         // [NB][2h][2w][2]
+  int NB, h, w;
+};
+
+// v = r + up  (pyramid_flow_estimator.py:161, util.py:114)
+struct FlowAddParams {
+  const float* a;
+  const float* b;
+  float* out;
+  int64_t n;          // floats
+};
+
+// util.warp (util.py:48-82 -> tfa.image.dense_image_warp): backward bilinear gather with
+// edge clamp.  flow is (dx,dy); the sampled position is (y + s*flow_y, x + s*flow_x).
+struct WarpParams {
+  const float* src;
+  int sstride;
+  int C;              // multiple of 4, or exactly 3
+  const float* flow;  // [NB][H][W][2]
+  float fscale;       // 1 in the flow estimator, 0.5 for the mid-frame warps (interpolator.py:163-165)
+  float* dst;
+  int dstride;
+  int NB, H, W;
+};
+
+// Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:
+// backward_flow*0.5 (2), forward_flow*0.5 (2), zeros (6)  (interpolator.py:163-165,182-183).
+struct PackFlowParams {
+  const float* bflow;  // [B][H][W][2]
+  const float* fflow;
+  float* dst;          // first misc channel + 6
+  int dstride;
+  int64_t npix;
+};
+
+enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
+                TILE_COUNT = 5 };
+
+struct TileShape { int bm, bn; };
+static inline TileShape film_tile_shape(int tile) {
+  switch (tile) {
+    case TILE_128x128: return {128, 128};
+    case TILE_256x64: return {256, 64};
+    case TILE_256x32: return {256, 32};
+    case TILE_64x64: return {64, 64};
+    default: return {128, 32};
+  }
+}
+
+hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s);
+hipError_t film_launch_conv_c3(const ConvC3Params& p, hipStream_t s);
+hipError_t film_launch_conv_pw(const ConvPwParams& p, hipStream_t s);
+hipError_t film_launch_pool(const PoolParams& p, hipStream_t s);
+hipError_t film_launch_flow_up(const FlowUpParams& p, hipStream_t s);
+hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s);
+hipError_t film_launch_warp(const WarpParams& p, hipStream_t s);
+hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s);

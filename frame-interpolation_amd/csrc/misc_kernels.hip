@@ -1,0 +1,330 @@
+// misc_kernels.hip -- the HBM-bound / small kernels of the FILM hot path (gfx950, wave64).
+//
+//   conv_c3      first layer, Conv2D 3x3 on the RGB image        feature_extractor.py:119-120
+//   conv_pw      1x1 Conv2D with Cout <= 16 (flow / RGB heads)   pyramid_flow_estimator.py:77-83, fusion.py:100-101
+//   pool2x2      AveragePooling2D(2,2,'valid')                   util.py:39-44, feature_extractor.py:138-146
+//   flow_up      tf.image.resize(2*v) bilinear x2                pyramid_flow_estimator.py:155, util.py:113
+//   flow_add     v = residual + v                                pyramid_flow_estimator.py:161, util.py:114
+//   warp         util.warp -> tfa.image.dense_image_warp         util.py:48-82
+//   pack_flow    0.5*flow into the aligned pyramid               interpolator.py:163-165,182-183
+//
+// This file is compiled with -ffp-contract=off: the reference evaluates every lerp as separate
+// multiply / add tensor ops (one rounding each), so a*b+c must not become an fma here.
+#include "film_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * v; }
+
+// ------------------------------------------------------------------------------------------------
+// conv_c3: thread = (pixel, 4 output channels); the 27 x Cout weights live in LDS.
+// Sum order: taps row-major, then channel -- the same K order as the MFMA kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_c3_kernel(ConvC3Params p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [27][Cout]
+  const int nw = 27 * p.Cout;
+  for (int i = threadIdx.x; i < nw; i += 256) wsm[i] = p.w[i];
+  __syncthreads();
+  const int G = p.Cout >> 2;
+  const int64_t total = (int64_t)p.NB * p.H * p.W * G;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % G);
+  const int64_t pix = idx / G;
+  const int x = (int)(pix % p.W);
+  const int64_t t2 = pix / p.W;
+  const int y = (int)(t2 % p.H);
+  const int64_t b = t2 / p.H;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int yy = y + dy - 1, xx = x + dx - 1;
+      const bool inb = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+      const float* src = p.in + ((b * p.H + (inb ? yy : 0)) * p.W + (inb ? xx : 0)) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float v = inb ? src[c] : 0.f;
+        const float4 w = *reinterpret_cast<const float4*>(wsm + ((dy * 3 + dx) * 3 + c) * p.Cout + g * 4);
+        acc.x = __builtin_fmaf(v, w.x, acc.x);
+        acc.y = __builtin_fmaf(v, w.y, acc.y);
+        acc.z = __builtin_fmaf(v, w.z, acc.z);
+        acc.w = __builtin_fmaf(v, w.w, acc.w);
+      }
+    }
+  }
+  const float4 bv = *reinterpret_cast<const float4*>(p.bias + g * 4);
+  acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
+  if (p.leaky) { acc.x = leaky02(acc.x); acc.y = leaky02(acc.y); acc.z = leaky02(acc.z); acc.w = leaky02(acc.w); }
+  *reinterpret_cast<float4*>(p.out + pix * p.ostride + g * 4) = acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_pw: thread = pixel, all COUT (<= 16) outputs in registers; weights broadcast from LDS.
+// ------------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void conv_pw_kernel(ConvPwParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Cin][COUT]
+  const int nw = p.Cin * COUT;
+  for (int i = threadIdx.x; i < nw; i += 256) wsm[i] = p.w[i];
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  const float* src = p.in + m * p.istride;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = 0.f;
+  for (int c = 0; c < p.Cin; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + c);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int o = 0; o < COUT; ++o) acc[o] = __builtin_fmaf(vv[k], wsm[(c + k) * COUT + o], acc[o]);
+    }
+  }
+  float* dst = p.out + m * p.ostride;
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    float v = acc[o] + p.bias[o];
+    if (p.leaky) v = leaky02(v);
+    dst[o] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pool2x2: thread = (output pixel, float4 channel group) or (output pixel) for C == 3.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pool_vec_kernel(PoolParams p) {
+  const int G = p.C >> 2;
+  const int Ho = p.H >> 1, Wo = p.W >> 1;
+  const int64_t total = (int64_t)p.NB * Ho * Wo * G;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % G);
+  const int64_t pix = idx / G;
+  const int x = (int)(pix % Wo);
+  const int64_t t2 = pix / Wo;
+  const int y = (int)(t2 % Ho);
+  const int64_t b = t2 / Ho;
+  const float* s00 = p.in + ((b * p.H + 2 * y) * p.W + 2 * x) * p.istride + g * 4;
+  const float4 a = *reinterpret_cast<const float4*>(s00);
+  const float4 bq = *reinterpret_cast<const float4*>(s00 + p.istride);
+  const float4 c = *reinterpret_cast<const float4*>(s00 + (int64_t)p.W * p.istride);
+  const float4 d = *reinterpret_cast<const float4*>(s00 + (int64_t)p.W * p.istride + p.istride);
+  float4 r;
+  r.x = (((a.x + bq.x) + c.x) + d.x) * 0.25f;
+  r.y = (((a.y + bq.y) + c.y) + d.y) * 0.25f;
+  r.z = (((a.z + bq.z) + c.z) + d.z) * 0.25f;
+  r.w = (((a.w + bq.w) + c.w) + d.w) * 0.25f;
+  *reinterpret_cast<float4*>(p.out + pix * p.ostride + g * 4) = r;
+}
+
+__global__ __launch_bounds__(256) void pool_c3_kernel(PoolParams p) {
+  const int Ho = p.H >> 1, Wo = p.W >> 1;
+  const int64_t total = (int64_t)p.NB * Ho * Wo;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int x = (int)(pix % Wo);
+  const int64_t t2 = pix / Wo;
+  const int y = (int)(t2 % Ho);
+  const int64_t b = t2 / Ho;
+  const float* s00 = p.in + ((b * p.H + 2 * y) * p.W + 2 * x) * p.istride;
+  const float* s10 = s00 + (int64_t)p.W * p.istride;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    p.out[pix * p.ostride + c] = (((s00[c] + s00[p.istride + c]) + s10[c]) + s10[p.istride + c]) * 0.25f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow_up: out = bilinear_x2(2 * in), TF2 half-pixel-centre rule.
+//   src = (o + 0.5) * 0.5 - 0.5; lo = max(floor(src), 0); hi = min(ceil(src), n - 1); t = src - floor(src)
+//   top = tl + (tr - tl) * tx; bot = bl + (br - bl) * tx; out = top + (bot - top) * ty
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void axis_x2(int o, int n, int& lo, int& hi, float& t) {
+  const float src = ((float)o + 0.5f) * 0.5f - 0.5f;
+  const float f = floorf(src);
+  lo = max((int)f, 0);
+  hi = min((int)ceilf(src), n - 1);
+  t = src - f;
+}
+
+__global__ __launch_bounds__(256) void flow_up_kernel(FlowUpParams p) {
+  const int Ho = p.h * 2, Wo = p.w * 2;
+  const int64_t total = (int64_t)p.NB * Ho * Wo;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int x = (int)(pix % Wo);
+  const int64_t t2 = pix / Wo;
+  const int y = (int)(t2 % Ho);
+  const int64_t b = t2 / Ho;
+  int ylo, yhi, xlo, xhi;
+  float ty, tx;
+  axis_x2(y, p.h, ylo, yhi, ty);
+  axis_x2(x, p.w, xlo, xhi, tx);
+  const float2* img = reinterpret_cast<const float2*>(p.in) + b * p.h * p.w;
+  float2 tl = img[(int64_t)ylo * p.w + xlo], tr = img[(int64_t)ylo * p.w + xhi];
+  float2 bl = img[(int64_t)yhi * p.w + xlo], br = img[(int64_t)yhi * p.w + xhi];
+  float2 o;
+  {
+    const float a = 2.f * tl.x, bq = 2.f * tr.x, c = 2.f * bl.x, d = 2.f * br.x;
+    const float top = a + (bq - a) * tx, bot = c + (d - c) * tx;
+    o.x = top + (bot - top) * ty;
+  }
+  {
+    const float a = 2.f * tl.y, bq = 2.f * tr.y, c = 2.f * bl.y, d = 2.f * br.y;
+    const float top = a + (bq - a) * tx, bot = c + (d - c) * tx;
+    o.y = top + (bot - top) * ty;
+  }
+  reinterpret_cast<float2*>(p.out)[pix] = o;
+}
+
+__global__ __launch_bounds__(256) void flow_add_kernel(FlowAddParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.n) return;
+  p.out[i] = p.a[i] + p.b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// warp: TFA dense_image_warp / interpolate_bilinear semantics, per axis
+//   q = coord + s*flow; f = min(max(floor(q), 0), size-2); alpha = clip(q - f, 0, 1)
+//   top = ax*(tr - tl) + tl; bot = ax*(br - bl) + bl; out = ay*(bot - top) + top
+// thread = (pixel, float4 channel group): lanes of a wave cover consecutive channel groups of the
+// same pixel, so the four corner reads and the store are contiguous 16-B-per-lane accesses.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void warp_axis(float q, int size, int& f, float& alpha) {
+  float fl = floorf(q);
+  fl = fminf(fmaxf(fl, 0.f), (float)(size - 2));
+  f = (int)fl;
+  alpha = fminf(fmaxf(q - fl, 0.f), 1.f);
+}
+
+__device__ __forceinline__ float lerp3(float tl, float tr, float bl, float br, float ax, float ay) {
+  const float top = ax * (tr - tl) + tl;
+  const float bot = ax * (br - bl) + bl;
+  return ay * (bot - top) + top;
+}
+
+__global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
+  const int G = p.C >> 2;
+  const int64_t total = (int64_t)p.NB * p.H * p.W * G;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int g = (int)(idx % G);
+  const int64_t pix = idx / G;
+  const int x = (int)(pix % p.W);
+  const int64_t t2 = pix / p.W;
+  const int y = (int)(t2 % p.H);
+  const int64_t b = t2 / p.H;
+  const float2 fl = reinterpret_cast<const float2*>(p.flow)[pix];
+  const float qy = (float)y + p.fscale * fl.y;
+  const float qx = (float)x + p.fscale * fl.x;
+  int fy, fx;
+  float ay, ax;
+  warp_axis(qy, p.H, fy, ay);
+  warp_axis(qx, p.W, fx, ax);
+  const float* s00 = p.src + ((b * p.H + fy) * p.W + fx) * p.sstride + g * 4;
+  const float4 tl = *reinterpret_cast<const float4*>(s00);
+  const float4 tr = *reinterpret_cast<const float4*>(s00 + p.sstride);
+  const float4 bl = *reinterpret_cast<const float4*>(s00 + (int64_t)p.W * p.sstride);
+  const float4 br = *reinterpret_cast<const float4*>(s00 + (int64_t)p.W * p.sstride + p.sstride);
+  float4 o;
+  o.x = lerp3(tl.x, tr.x, bl.x, br.x, ax, ay);
+  o.y = lerp3(tl.y, tr.y, bl.y, br.y, ax, ay);
+  o.z = lerp3(tl.z, tr.z, bl.z, br.z, ax, ay);
+  o.w = lerp3(tl.w, tr.w, bl.w, br.w, ax, ay);
+  *reinterpret_cast<float4*>(p.dst + pix * p.dstride + g * 4) = o;
+}
+
+__global__ __launch_bounds__(256) void warp_c3_kernel(WarpParams p) {
+  const int64_t total = (int64_t)p.NB * p.H * p.W;
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= total) return;
+  const int x = (int)(pix % p.W);
+  const int64_t t2 = pix / p.W;
+  const int y = (int)(t2 % p.H);
+  const int64_t b = t2 / p.H;
+  const float2 fl = reinterpret_cast<const float2*>(p.flow)[pix];
+  const float qy = (float)y + p.fscale * fl.y;
+  const float qx = (float)x + p.fscale * fl.x;
+  int fy, fx;
+  float ay, ax;
+  warp_axis(qy, p.H, fy, ay);
+  warp_axis(qx, p.W, fx, ax);
+  const float* s00 = p.src + ((b * p.H + fy) * p.W + fx) * p.sstride;
+  const float* s10 = s00 + (int64_t)p.W * p.sstride;
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+    p.dst[pix * p.dstride + c] = lerp3(s00[c], s00[p.sstride + c], s10[c], s10[p.sstride + c], ax, ay);
+}
+
+__global__ __launch_bounds__(256) void pack_flow_kernel(PackFlowParams p) {
+  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.npix) return;
+  const float2 bf = reinterpret_cast<const float2*>(p.bflow)[pix];
+  const float2 ff = reinterpret_cast<const float2*>(p.fflow)[pix];
+  float* d = p.dst + pix * p.dstride;
+  d[0] = bf.x * 0.5f; d[1] = bf.y * 0.5f;
+  d[2] = ff.x * 0.5f; d[3] = ff.y * 0.5f;
+#pragma unroll
+  for (int i = 4; i < 10; ++i) d[i] = 0.f;
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
+
+}  // namespace
+
+hipError_t film_launch_conv_c3(const ConvC3Params& p, hipStream_t s) {
+  const int64_t total = (int64_t)p.NB * p.H * p.W * (p.Cout / 4);
+  hipLaunchKernelGGL(conv_c3_kernel, dim3(blocks_for(total)), dim3(256), 27 * p.Cout * sizeof(float), s, p);
+  return hipGetLastError();
+}
+
+hipError_t film_launch_conv_pw(const ConvPwParams& p, hipStream_t s) {
+  const dim3 grid(blocks_for(p.M)), block(256);
+  const size_t sh = (size_t)p.Cin * p.Cout * sizeof(float);
+  switch (p.Cout) {
+    case 2: hipLaunchKernelGGL(conv_pw_kernel<2>, grid, block, sh, s, p); break;
+    case 3: hipLaunchKernelGGL(conv_pw_kernel<3>, grid, block, sh, s, p); break;
+    case 16: hipLaunchKernelGGL(conv_pw_kernel<16>, grid, block, sh, s, p); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+hipError_t film_launch_pool(const PoolParams& p, hipStream_t s) {
+  const int64_t opix = (int64_t)p.NB * (p.H / 2) * (p.W / 2);
+  if (p.C == 3) {
+    hipLaunchKernelGGL(pool_c3_kernel, dim3(blocks_for(opix)), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(pool_vec_kernel, dim3(blocks_for(opix * (p.C / 4))), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t film_launch_flow_up(const FlowUpParams& p, hipStream_t s) {
+  const int64_t opix = (int64_t)p.NB * p.h * 2 * p.w * 2;
+  hipLaunchKernelGGL(flow_up_kernel, dim3(blocks_for(opix)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(flow_add_kernel, dim3(blocks_for(p.n)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
+  const int64_t npix = (int64_t)p.NB * p.H * p.W;
+  if (p.C == 3) {
+    hipLaunchKernelGGL(warp_c3_kernel, dim3(blocks_for(npix)), dim3(256), 0, s, p);
+  } else {
+    hipLaunchKernelGGL(warp_vec_kernel, dim3(blocks_for(npix * (p.C / 4))), dim3(256), 0, s, p);
+  }
+  return hipGetLastError();
+}
+
+hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(pack_flow_kernel, dim3(blocks_for(p.npix)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}

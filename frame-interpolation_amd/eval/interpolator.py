@@ -1,0 +1,156 @@
+"""Drop-in for the reference's eval/interpolator.py, backed by the MI355X HIP engine.
+
+Usage (unchanged from the reference, eval/interpolator.py:15-24):
+  model_path='/tmp/saved_model/'
+  it = Interpolator(model_path)
+  result_batch = it.interpolate(image_batch_0, image_batch_1, batch_dt)
+
+  image_batch_* are numpy float32 tensors in (B,H,W,C) layout, batch_dt is the sub-frame time,
+  (B,) layout (ignored by film_net, which always predicts t=0.5 -
+  models/film_net/interpolator.py:102,163).
+
+What changed underneath: ``tf.saved_model.load`` + ``self._model(...)`` (reference
+eval/interpolator.py:148,170-172) are replaced by ``film_create/film_set_weight/film_finalize`` +
+``film_forward`` of libfilm_hip.so (include/film_hip.h).  Padding, cropping and patch
+(un)folding are host-side numpy, with the reference's exact layout rules; the patches of a tiled
+frame are independent (reference loops over them with B=1, :199-202) and are sent to the GPU as
+ONE batch.  There is no TensorFlow and no CPU fallback: without the built library and a gfx950
+device, construction raises.
+"""
+from typing import List, Optional
+
+import numpy as np
+
+from film_hip import weights as weights_lib
+from film_hip.engine import FilmEngine
+from film_hip.options import Options, PUBLISHED
+
+
+def _pad_to_align(x, align):
+  """Zero-pads H and W of a [B,H,W,C] batch up to multiples of `align`, centred with offset
+  pad // 2 (reference eval/interpolator.py:30-63, tf.image.pad_to_bounding_box).  Returns the
+  padded batch and the crop box that undoes it."""
+  assert np.ndim(x) == 4
+  assert align > 0, 'align must be a positive number.'
+
+  height, width = x.shape[-3:-1]
+  height_to_pad = (align - height % align) if height % align != 0 else 0
+  width_to_pad = (align - width % align) if width % align != 0 else 0
+  off_h, off_w = height_to_pad // 2, width_to_pad // 2
+  if height_to_pad or width_to_pad:
+    padded_x = np.zeros((x.shape[0], height + height_to_pad, width + width_to_pad, x.shape[3]), dtype=x.dtype)
+    padded_x[:, off_h:off_h + height, off_w:off_w + width, :] = x
+  else:
+    padded_x = x
+  bbox_to_crop = {
+      'offset_height': off_h,
+      'offset_width': off_w,
+      'target_height': height,
+      'target_width': width
+  }
+  return padded_x, bbox_to_crop
+
+
+def _crop_to_bounding_box(image, offset_height, offset_width, target_height, target_width):
+  return image[:, offset_height:offset_height + target_height, offset_width:offset_width + target_width, :]
+
+
+def image_to_patches(image: np.ndarray, block_shape: List[int]) -> np.ndarray:
+  """[.., H, W, C] image -> [bh*bw, H/bh, W/bw, C]: row-major, non-overlapping blocks (what the
+  reference's tf.space_to_batch construction yields, eval/interpolator.py:66-99)."""
+  block_height, block_width = block_shape
+  num_blocks = block_height * block_width
+
+  height, width, channel = image.shape[-3:]
+  patch_height, patch_width = height // block_height, width // block_width
+
+  assert height == (
+      patch_height * block_height
+  ), 'block_height=%d should evenly divide height=%d.' % (block_height, height)
+  assert width == (
+      patch_width * block_width
+  ), 'block_width=%d should evenly divide width=%d.' % (block_width, width)
+
+  img = np.reshape(image, (-1, height, width, channel))[0]
+  patches = img.reshape(block_height, patch_height, block_width, patch_width, channel)
+  patches = patches.transpose(0, 2, 1, 3, 4)
+  return np.ascontiguousarray(patches.reshape(num_blocks, patch_height, patch_width, channel))
+
+
+def patches_to_image(patches: np.ndarray, block_shape: List[int]) -> np.ndarray:
+  """Unfolds patches (stacked along batch) into an image [1, H, W, C] (eval/interpolator.py:102-126)."""
+  block_height, block_width = block_shape
+  patch_height, patch_width, channel = patches.shape[-3:]
+  image = patches.reshape(block_height, block_width, patch_height, patch_width, channel)
+  image = image.transpose(0, 2, 1, 3, 4)
+  return np.ascontiguousarray(
+      image.reshape(1, block_height * patch_height, block_width * patch_width, channel))
+
+
+class Interpolator:
+  """A class for generating interpolated frames between two input frames.
+
+  Same constructor and call signatures as the reference class (eval/interpolator.py:129-209).
+  """
+
+  def __init__(self, model_path: str,
+               align: Optional[int] = None,
+               block_shape: Optional[List[int]] = None,
+               *, device: int = 0, options: Optional[Options] = None,
+               weights=None) -> None:
+    """Loads the weights of a saved model into a HIP engine.
+
+    Args:
+      model_path: directory of the model: a TF2 SavedModel (variables bundle) or a directory
+        holding film_weights.npz (see film_hip.weights.load_weights).
+      align: 'If >1, pad the input size so it divides with this before inference.'
+      block_shape: Number of patches along the (height, width) to sid-divide input images.
+      device: (extension) HIP device ordinal.
+      options: (extension) architecture hyper-parameters; default = published film_net.
+      weights: (extension) an already loaded {name: array} dict; model_path is then ignored.
+    """
+    self._options = options or PUBLISHED
+    if weights is None:
+      weights = weights_lib.load_weights(model_path)
+    weights_lib.validate_weights(weights, self._options)
+    self._engine = FilmEngine(self._options, device=device)
+    self._engine.set_weights(weights)
+    self._align = align or None
+    self._block_shape = block_shape or None
+
+  @property
+  def engine(self) -> FilmEngine:
+    return self._engine
+
+  def interpolate(self, x0: np.ndarray, x1: np.ndarray,
+                  dt: np.ndarray) -> np.ndarray:
+    """Mid-frame for every pair of the batch (reference: Interpolator.interpolate, :152-176).
+
+    x0, x1 are float32 [B,H,W,3]; dt is [B] and unused by film_net.  Pads to `align`, runs one
+    film_forward on the GPU, crops back.  Output is float32 [B,H,W,3], NOT clipped to [0,1].
+    """
+    if self._align is not None:
+      x0, bbox_to_crop = _pad_to_align(x0, self._align)
+      x1, _ = _pad_to_align(x1, self._align)
+
+    image = self._engine.forward(x0, x1)
+
+    if self._align is not None:
+      image = np.ascontiguousarray(_crop_to_bounding_box(image, **bbox_to_crop))
+    return image
+
+  def __call__(self, x0: np.ndarray, x1: np.ndarray,
+               dt: np.ndarray) -> np.ndarray:
+    """Same contract as interpolate(); with block_shape set, the (single) image is split into
+    non-overlapping patches that are padded, interpolated and cropped independently and then
+    stitched back (reference: Interpolator.__call__, :178-209)."""
+    if self._block_shape is not None and np.prod(self._block_shape) > 1:
+      x0_patches = image_to_patches(x0, self._block_shape)
+      x1_patches = image_to_patches(x1, self._block_shape)
+
+      # The reference runs the patches one by one with B=1; they are independent, so all of
+      # them go through the engine as one batch (identical per-patch arithmetic).
+      output_patches = self.interpolate(x0_patches, x1_patches, dt)
+
+      return patches_to_image(output_patches, self._block_shape)
+    return self.interpolate(x0, x1, dt)

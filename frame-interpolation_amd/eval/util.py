@@ -1,0 +1,114 @@
+"""Host-side frame IO and the recursive mid-point driver (mirror of the reference's eval/util.py).
+
+Same function names, arguments and rounding rules as the reference module; TensorFlow's image codecs
+(tf.io.decode_image / encode_png / encode_jpeg, reference eval/util.py:38-59) are replaced by PIL.
+"""
+import os
+import shutil
+from typing import Generator, Iterable, List, Optional
+
+import numpy as np
+
+from . import interpolator as interpolator_lib
+
+try:
+    from tqdm import tqdm
+except Exception:  # pragma: no cover
+    tqdm = None
+
+_UINT8_MAX_F = float(np.iinfo(np.uint8).max)
+_CONFIG_FFMPEG_NAME_OR_PATH = 'ffmpeg'
+
+
+def _pil():
+    from PIL import Image, PngImagePlugin
+    # photos/one.png carries a very large zTXt chunk; PIL refuses it by default.
+    PngImagePlugin.MAX_TEXT_CHUNK = max(PngImagePlugin.MAX_TEXT_CHUNK, 256 * 1024 * 1024)
+    Image.MAX_IMAGE_PIXELS = None
+    return Image
+
+
+def read_image(filename: str) -> np.ndarray:
+    """8-bit sRGB file -> float32 [H,W,3] in [0,1] (uint8 / 255, reference eval/util.py:29-41)."""
+    with _pil().open(filename) as im:
+        rgb = np.asarray(im.convert('RGB'), dtype=np.uint8)
+    return rgb.astype(np.float32) / _UINT8_MAX_F
+
+
+def to_uint8(image: np.ndarray) -> np.ndarray:
+    """clip(x*255, 0, 255) + 0.5, truncated to uint8 - the reference's rounding (eval/util.py:51-52)."""
+    scaled = np.clip(image * _UINT8_MAX_F, 0.0, _UINT8_MAX_F)
+    return (scaled + 0.5).astype(np.uint8)
+
+
+def write_image(filename: str, image: np.ndarray) -> None:
+    """float32 [H,W,3] in [0,1] -> .jpg when the extension says so, PNG otherwise (eval/util.py:44-59)."""
+    pixels = to_uint8(image)
+    Image = _pil()
+    extension = os.path.splitext(filename)[1]
+    if extension == '.jpg':
+        Image.fromarray(pixels, 'RGB').save(filename, format='JPEG', quality=95)
+    else:
+        Image.fromarray(pixels, 'RGB').save(filename, format='PNG')
+
+
+def _recursive_generator(
+        frame1: np.ndarray, frame2: np.ndarray, num_recursions: int,
+        interpolator: 'interpolator_lib.Interpolator',
+        bar=None) -> Generator[np.ndarray, None, None]:
+    """Depth-first binary subdivision (reference eval/util.py:62-91).
+
+    Yields frame1, then every generated frame in temporal order, but not frame2.  Each mid-frame is
+    one interpolator call with batch size 1 and time 0.5; the raw (un-clipped) float result is what
+    deeper recursion levels consume, exactly as upstream.
+    """
+    if num_recursions == 0:
+        yield frame1
+        return
+    time = np.full(shape=(1,), fill_value=0.5, dtype=np.float32)
+    mid_frame = interpolator(frame1[np.newaxis, ...], frame2[np.newaxis, ...], time)[0]
+    if bar is not None:
+        bar.update(1)
+    yield from _recursive_generator(frame1, mid_frame, num_recursions - 1, interpolator, bar)
+    yield from _recursive_generator(mid_frame, frame2, num_recursions - 1, interpolator, bar)
+
+
+def _progress(total: int):
+    if tqdm is None:
+        return None
+    return tqdm(total=total, ncols=100, colour='green')
+
+
+def interpolate_recursively_from_files(
+        frames: List[str], times_to_interpolate: int,
+        interpolator: 'interpolator_lib.Interpolator') -> Iterable[np.ndarray]:
+    """Streams (n-1)*(2^T-1) generated frames plus the n inputs, reading files lazily
+    (reference eval/util.py:94-123)."""
+    n = len(frames)
+    bar = _progress((n - 1) * (2 ** times_to_interpolate - 1))
+    for i in range(1, n):
+        yield from _recursive_generator(
+            read_image(frames[i - 1]), read_image(frames[i]), times_to_interpolate, interpolator, bar)
+    yield read_image(frames[-1])
+
+
+def interpolate_recursively_from_memory(
+        frames: List[np.ndarray], times_to_interpolate: int,
+        interpolator: 'interpolator_lib.Interpolator') -> Iterable[np.ndarray]:
+    """Same as interpolate_recursively_from_files for frames already in memory
+    (reference eval/util.py:125-153)."""
+    n = len(frames)
+    bar = _progress((n - 1) * (2 ** times_to_interpolate - 1))
+    for i in range(1, n):
+        yield from _recursive_generator(frames[i - 1], frames[i], times_to_interpolate, interpolator, bar)
+    yield frames[-1]
+
+
+def get_ffmpeg_path() -> str:
+    """reference eval/util.py:156-162."""
+    path = shutil.which(_CONFIG_FFMPEG_NAME_OR_PATH)
+    if not path:
+        raise RuntimeError(
+            f"Program '{_CONFIG_FFMPEG_NAME_OR_PATH}' is not found;"
+            " perhaps install ffmpeg using 'apt-get install ffmpeg'.")
+    return path

@@ -1,0 +1,55 @@
+"""Builds libfilm_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+  python -m film_hip.build          (from frame-interpolation_amd/)
+  make -C frame-interpolation_amd/csrc   (equivalent)
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
+OUT = os.path.join(_HERE, 'libfilm_hip.so')
+SOURCES = ['conv_igemm.hip', 'misc_kernels.hip', 'film_engine.cpp']
+HEADERS = ['film_kernels.h', os.path.join('..', '..', 'include', 'film_hip.h')]
+FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.isfile(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get('HIPCC', 'hipcc')
+    bdir = os.path.join(CSRC, 'build')
+    os.makedirs(bdir, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(bdir, os.path.splitext(src)[0] + '.o')
+        objs.append(obj)
+        if force or _stale(obj, [sp] + hdrs):
+            cmd = [hipcc] + FLAGS + ['-c', sp, '-o', obj]
+            if verbose:
+                print(' '.join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC)))
+    for cmd, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
+    if force or procs or _stale(OUT, objs):
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd, cwd=CSRC)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

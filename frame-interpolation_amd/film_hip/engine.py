@@ -1,0 +1,216 @@
+"""ctypes binding of libfilm_hip.so (C-ABI: include/film_hip.h).
+
+This is the whole Python <-> native boundary of the product path: plain pointers and sizes.
+If the shared library is missing or no MI355X is visible, construction FAILS LOUDLY - there is no
+CPU or PyTorch fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes
+import json
+import os
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+from .options import Options, PUBLISHED
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libfilm_hip.so')
+
+FILM_MEM_HOST = 0
+FILM_MEM_DEVICE = 1
+FILM_ERR_INVALID = -1
+FILM_ERR_NO_DEVICE = -3
+_MAXS = 8
+
+
+class FilmError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f'libfilm_hip error {code}: {msg}')
+        self.code = code
+        self.msg = msg
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [('pyramid_levels', ctypes.c_int32), ('fusion_pyramid_levels', ctypes.c_int32),
+                ('specialized_levels', ctypes.c_int32), ('sub_levels', ctypes.c_int32),
+                ('filters', ctypes.c_int32), ('flow_convs', ctypes.c_int32 * _MAXS),
+                ('flow_filters', ctypes.c_int32 * _MAXS)]
+
+
+# every symbol include/film_hip.h declares; tests assert the library exports all of them
+EXPORTED_SYMBOLS = (
+    'film_default_config', 'film_create', 'film_destroy', 'film_last_error', 'film_set_weight',
+    'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_forward',
+    'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_version')
+
+_lib = None
+
+
+def load_library(path: Optional[str] = None) -> ctypes.CDLL:
+    """dlopen()s the engine; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.isfile(p):
+        raise FileNotFoundError(
+            f'{p} not found: build the HIP engine first (python -c "import __graft_entry__ as g; g.build()" '
+            'or make -C frame-interpolation_amd/csrc). There is no CPU fallback.')
+    lib = ctypes.CDLL(p)
+    vp, cp, i64p, fp = ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p
+    lib.film_default_config.argtypes = [ctypes.POINTER(_Config)]
+    lib.film_create.argtypes = [ctypes.POINTER(vp), ctypes.c_int, ctypes.POINTER(_Config)]
+    lib.film_destroy.argtypes = [vp]
+    lib.film_destroy.restype = None
+    lib.film_last_error.argtypes = [vp]
+    lib.film_last_error.restype = cp
+    lib.film_set_weight.argtypes = [vp, cp, fp, i64p, ctypes.c_int]
+    lib.film_finalize.argtypes = [vp]
+    lib.film_packed_size.argtypes = [vp, i64p]
+    lib.film_export_packed.argtypes = [vp, fp, ctypes.c_int64, ctypes.c_int]
+    lib.film_import_packed.argtypes = [vp, fp, ctypes.c_int64, ctypes.c_int]
+    lib.film_forward.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, vp]
+    lib.film_set_option.argtypes = [vp, cp, ctypes.c_int64]
+    lib.film_profile_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, i64p]
+    lib.film_plan_json.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, i64p]
+    lib.film_get_tap.argtypes = [vp, cp, fp, ctypes.c_int64, i64p]
+    lib.film_version.argtypes = []
+    lib.film_version.restype = cp
+    for name in EXPORTED_SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is ctypes.c_int and name not in ('film_destroy',):
+            fn.restype = ctypes.c_int
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _cfg_struct(opt: Options) -> _Config:
+    opt.validate()
+    c = _Config()
+    c.pyramid_levels, c.fusion_pyramid_levels = opt.pyramid_levels, opt.fusion_pyramid_levels
+    c.specialized_levels, c.sub_levels, c.filters = opt.specialized_levels, opt.sub_levels, opt.filters
+    for i, (a, b) in enumerate(zip(opt.flow_convs, opt.flow_filters)):
+        c.flow_convs[i] = a
+        c.flow_filters[i] = b
+    return c
+
+
+class FilmEngine:
+    """One engine = one GPU + one stream + packed weights + cached per-shape plans.
+
+    ``device=-1`` gives a plan-only handle (no GPU needed): it can pack weights and describe plans
+    but every compute call raises FilmError(FILM_ERR_NO_DEVICE)."""
+
+    def __init__(self, opt: Options = PUBLISHED, device: int = 0):
+        self._lib = load_library()
+        self._opt = opt
+        self._h = ctypes.c_void_p()
+        cfg = _cfg_struct(opt)
+        rc = self._lib.film_create(ctypes.byref(self._h), device, ctypes.byref(cfg))
+        if rc != 0:
+            msg = self._lib.film_last_error(None).decode()
+            self._h = ctypes.c_void_p()
+            raise FilmError(rc, msg)
+        self.device = device
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, '_h', None) is not None and self._h.value:
+            self._lib.film_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc != 0:
+            raise FilmError(rc, self._lib.film_last_error(self._h).decode())
+
+    @property
+    def options(self) -> Options:
+        return self._opt
+
+    # -- weights ----------------------------------------------------------------------------
+    def set_weights(self, weights: Dict[str, np.ndarray]) -> None:
+        """weights: canonical name -> HWIO kernel / bias (film_hip.weights)."""
+        for name, arr in weights.items():
+            a = np.ascontiguousarray(arr, dtype=np.float32)
+            dims = (ctypes.c_int64 * a.ndim)(*a.shape)
+            self._check(self._lib.film_set_weight(self._h, name.encode(), a.ctypes.data, dims, a.ndim))
+        self._check(self._lib.film_finalize(self._h))
+
+    def packed_size(self) -> int:
+        n = ctypes.c_int64()
+        self._check(self._lib.film_packed_size(self._h, ctypes.byref(n)))
+        return n.value
+
+    def export_packed(self) -> np.ndarray:
+        out = np.empty(self.packed_size(), dtype=np.float32)
+        self._check(self._lib.film_export_packed(self._h, out.ctypes.data, out.size, FILM_MEM_HOST))
+        return out
+
+    def import_packed(self, blob: np.ndarray) -> None:
+        b = np.ascontiguousarray(blob, dtype=np.float32)
+        self._check(self._lib.film_import_packed(self._h, b.ctypes.data, b.size, FILM_MEM_HOST))
+
+    def import_packed_device(self, ptr: int, n_floats: int) -> None:
+        self._check(self._lib.film_import_packed(self._h, ctypes.c_void_p(ptr), n_floats, FILM_MEM_DEVICE))
+
+    def export_packed_device(self, ptr: int, n_floats: int) -> None:
+        self._check(self._lib.film_export_packed(self._h, ctypes.c_void_p(ptr), n_floats, FILM_MEM_DEVICE))
+
+    # -- compute ----------------------------------------------------------------------------
+    def forward(self, x0: np.ndarray, x1: np.ndarray) -> np.ndarray:
+        """x0, x1: float32 [B,H,W,3] host arrays -> [B,H,W,3] (un-clipped), t = 0.5."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32)
+        x1 = np.ascontiguousarray(x1, dtype=np.float32)
+        if x0.ndim != 4 or x0.shape[3] != 3 or x0.shape != x1.shape:
+            raise ValueError(f'expected two [B,H,W,3] arrays of equal shape, got {x0.shape} and {x1.shape}')
+        b, h, w, _ = x0.shape
+        out = np.empty_like(x0)
+        self._check(self._lib.film_forward(self._h, x0.ctypes.data, x1.ctypes.data, b, h, w,
+                                           out.ctypes.data, FILM_MEM_HOST, None))
+        return out
+
+    def forward_device(self, x0_ptr: int, x1_ptr: int, b: int, h: int, w: int, out_ptr: int,
+                       stream: Optional[int] = None) -> None:
+        """Device-resident variant: raw device pointers (e.g. torch.Tensor.data_ptr()); asynchronous
+        on `stream` (a hipStream_t as int, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._check(self._lib.film_forward(self._h, ctypes.c_void_p(x0_ptr), ctypes.c_void_p(x1_ptr), b, h, w,
+                                           ctypes.c_void_p(out_ptr), FILM_MEM_DEVICE,
+                                           ctypes.c_void_p(stream) if stream else None))
+
+    def set_option(self, key: str, value: int) -> None:
+        self._check(self._lib.film_set_option(self._h, key.encode(), int(value)))
+
+    # -- introspection ------------------------------------------------------------------------
+    def _json_call(self, fn, *args) -> dict:
+        need = ctypes.c_int64()
+        self._check(fn(self._h, *args, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        self._check(fn(self._h, *args, buf, need.value, ctypes.byref(need)))
+        return json.loads(buf.value.decode())
+
+    def plan(self, b: int, h: int, w: int) -> dict:
+        return self._json_call(self._lib.film_plan_json, b, h, w)
+
+    def profile(self) -> dict:
+        return self._json_call(self._lib.film_profile_json)
+
+    def tap(self, name: str) -> np.ndarray:
+        dims = (ctypes.c_int64 * 4)()
+        self._check(self._lib.film_get_tap(self._h, name.encode(), None, 0, dims))
+        shape = tuple(int(d) for d in dims)
+        out = np.empty(shape, dtype=np.float32)
+        self._check(self._lib.film_get_tap(self._h, name.encode(), out.ctypes.data, out.size, dims))
+        return out
+
+    @staticmethod
+    def version() -> str:
+        return load_library().film_version().decode()

@@ -1,0 +1,79 @@
+"""Device-resident plumbing around the engine: PyTorch-ROCm tensors for memory and streams only.
+
+The arithmetic of the hot path is entirely inside libfilm_hip.so; torch is used here to hold frames
+in HBM, to pad / crop / (un)fold patches on the device (pure data movement, the same rules as
+eval/interpolator.py) and to hand raw pointers + the current stream to ``film_forward``.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import torch
+
+from .engine import FilmEngine
+
+
+def pad_to_align(x: torch.Tensor, align: int) -> Tuple[torch.Tensor, Tuple[int, int, int, int]]:
+    """[B,H,W,C] -> zero padded to multiples of align, offset pad//2 (eval/interpolator.py:30-63)."""
+    b, h, w, c = x.shape
+    hp = (align - h % align) if h % align else 0
+    wp = (align - w % align) if w % align else 0
+    oy, ox = hp // 2, wp // 2
+    if hp == 0 and wp == 0:
+        return x.contiguous(), (0, 0, h, w)
+    out = torch.zeros((b, h + hp, w + wp, c), dtype=x.dtype, device=x.device)
+    out[:, oy:oy + h, ox:ox + w, :] = x
+    return out, (oy, ox, h, w)
+
+
+def image_to_patches(image: torch.Tensor, block_shape: List[int]) -> torch.Tensor:
+    """[1,H,W,C] -> [bh*bw, H/bh, W/bw, C], row-major blocks (eval/interpolator.py:66-99)."""
+    bh, bw = block_shape
+    _, h, w, c = image.shape
+    ph, pw = h // bh, w // bw
+    assert h == ph * bh, 'block_height=%d should evenly divide height=%d.' % (bh, h)
+    assert w == pw * bw, 'block_width=%d should evenly divide width=%d.' % (bw, w)
+    return image[0].reshape(bh, ph, bw, pw, c).permute(0, 2, 1, 3, 4).reshape(bh * bw, ph, pw, c).contiguous()
+
+
+def patches_to_image(patches: torch.Tensor, block_shape: List[int]) -> torch.Tensor:
+    """inverse of image_to_patches (eval/interpolator.py:102-126)."""
+    bh, bw = block_shape
+    _, ph, pw, c = patches.shape
+    return patches.reshape(bh, bw, ph, pw, c).permute(0, 2, 1, 3, 4).reshape(1, bh * ph, bw * pw, c).contiguous()
+
+
+class DeviceInterpolator:
+    """Interpolator.__call__ semantics (eval/interpolator.py:178-209) on frames that already live
+    in HBM: float32 CUDA(=HIP) tensors in, float32 CUDA tensor out, no host round trip.
+
+    Asynchronous on the current torch stream."""
+
+    def __init__(self, engine: FilmEngine, align: Optional[int] = None, block_shape: Optional[List[int]] = None):
+        self._engine = engine
+        self._align = align or None
+        self._block_shape = block_shape or None
+
+    def interpolate(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
+        assert x0.is_cuda and x0.dtype == torch.float32 and x0.shape == x1.shape and x0.shape[-1] == 3
+        box = None
+        if self._align is not None:
+            x0, box = pad_to_align(x0, self._align)
+            x1, _ = pad_to_align(x1, self._align)
+        x0 = x0.contiguous()
+        x1 = x1.contiguous()
+        b, h, w, _ = x0.shape
+        out = torch.empty_like(x0)
+        stream = torch.cuda.current_stream(x0.device).cuda_stream
+        self._engine.forward_device(x0.data_ptr(), x1.data_ptr(), b, h, w, out.data_ptr(), stream)
+        if box is not None:
+            oy, ox, th, tw = box
+            out = out[:, oy:oy + th, ox:ox + tw, :]
+        return out
+
+    def __call__(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
+        if self._block_shape is not None and self._block_shape[0] * self._block_shape[1] > 1:
+            p0 = image_to_patches(x0, self._block_shape)
+            p1 = image_to_patches(x1, self._block_shape)
+            return patches_to_image(self.interpolate(p0, p1).contiguous(), self._block_shape)
+        return self.interpolate(x0, x1).contiguous()

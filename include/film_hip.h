@@ -1,0 +1,128 @@
+/*
+ * film_hip.h  --  C-ABI of libfilm_hip.so, the MI355X (gfx950) FILM inference engine.
+ *
+ * This is the drop-in boundary for the reference's one operator call on the hot path:
+ *
+ *     self._model = tf.compat.v2.saved_model.load(model_path)        eval/interpolator.py:148
+ *     result = self._model({'x0','x1','time'}, training=False)       eval/interpolator.py:170-171
+ *     image  = result['image']                                       eval/interpolator.py:172
+ *
+ * i.e. "load the film_net weights" and "run models/film_net (interpolator.py:89-207) on a
+ * batch of frame pairs and return the t=0.5 frame".  Everything here is plain C: pointers
+ * and sizes, no torch / numpy types.  The Python host
+ * (frame-interpolation_amd/eval/interpolator.py) binds it with ctypes; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Tensors are NHWC float32, weights are TF HWIO [kh,kw,cin,cout] float32 (the layout a
+ * Keras SavedModel stores, training/train_lib.py:280).
+ *
+ * Every function returns 0 on success or a negative FILM_ERR_* code; the message is
+ * available from film_last_error().  A handle owns one device, one stream, the packed
+ * weights and a per-(B,H,W) cached execution plan + workspace.  Handles are not
+ * thread-safe; several handles may coexist.
+ */
+#ifndef FILM_HIP_H_
+#define FILM_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FILM_OK 0
+#define FILM_ERR_INVALID (-1)    /* bad argument / shape (reference: assert / ValueError)      */
+#define FILM_ERR_STATE (-2)      /* call order (e.g. forward before finalize)                   */
+#define FILM_ERR_NO_DEVICE (-3)  /* no HIP device: the engine has NO CPU fallback               */
+#define FILM_ERR_HIP (-4)        /* a HIP runtime call failed                                   */
+#define FILM_ERR_NOMEM (-5)
+#define FILM_ERR_NOTFOUND (-6)   /* unknown weight / tap name                                   */
+
+#define FILM_MEM_HOST 0   /* x0/x1/out are host pointers: H2D + D2H done by the call          */
+#define FILM_MEM_DEVICE 1 /* x0/x1/out are device pointers on the handle's device              */
+
+#define FILM_MAX_SPECIALIZED 7
+
+typedef struct film_handle film_t;
+
+/* models/film_net/options.py:20-80 ; defaults = training/config/film_net-L1.gin:17-23 */
+typedef struct film_config {
+  int32_t pyramid_levels;
+  int32_t fusion_pyramid_levels;
+  int32_t specialized_levels;
+  int32_t sub_levels;
+  int32_t filters;
+  int32_t flow_convs[FILM_MAX_SPECIALIZED + 1];   /* specialized_levels+1 entries used */
+  int32_t flow_filters[FILM_MAX_SPECIALIZED + 1]; /* specialized_levels+1 entries used */
+} film_config;
+
+/* Fills *cfg with the published architecture (film_net-L1.gin:17-23). */
+int film_default_config(film_config* cfg);
+
+/* Creates an engine on HIP device `device` (>= 0).
+ * device == -1 creates a PLAN-ONLY handle: it can take weights, pack them and describe
+ * plans (film_plan_json / film_export_packed) without a GPU, and every compute entry point
+ * returns FILM_ERR_NO_DEVICE.  There is no CPU execution path in this library.
+ * Replaces: tf.compat.v2.saved_model.load (eval/interpolator.py:148), object creation half. */
+int film_create(film_t** out, int device, const film_config* cfg);
+void film_destroy(film_t* h);
+
+/* Message of the last failing call on this handle (or of film_create when h == NULL). */
+const char* film_last_error(const film_t* h);
+
+/* Supplies one tensor by canonical name, e.g.
+ *   "feat_net/sub_extractor/cfeat_conv_0/kernel"  dims = {3,3,3,64}
+ *   "predict_flow/flow_predictor_shared/conv_4/bias"  dims = {2}
+ * (names: frame-interpolation_amd/film_hip/weights.py).  Data is copied.
+ * Replaces: the variable restore inside saved_model.load (eval/interpolator.py:148). */
+int film_set_weight(film_t* h, const char* name, const float* data, const int64_t* dims, int ndim);
+
+/* Checks that every tensor of the architecture is present with the right shape, repacks
+ * HWIO into the engine's K-major layout (zero-padding / permuting concat segments) and
+ * uploads the blob to the device. */
+int film_finalize(film_t* h);
+
+/* Packed weight blob (floats): size, export to / import from a caller buffer.  Import lets a
+ * rank that received the blob by RCCL broadcast skip film_set_weight + repacking. */
+int film_packed_size(film_t* h, int64_t* n_floats);
+int film_export_packed(film_t* h, float* dst, int64_t capacity_floats, int mem_kind);
+int film_import_packed(film_t* h, const float* src, int64_t n_floats, int mem_kind);
+
+/* Runs film_net on B frame pairs: x0, x1 [B,H,W,3] -> out [B,H,W,3] (un-clipped), t = 0.5.
+ * H and W must be divisible by 2^(pyramid_levels-1) (options.py:36-37) - pad first, as
+ * Interpolator.interpolate does (eval/interpolator.py:166-168).
+ * `stream`: a hipStream_t to run on, or NULL for the handle's own stream.  With
+ * FILM_MEM_HOST the call synchronises before returning; with FILM_MEM_DEVICE it is
+ * asynchronous on the stream.
+ * Replaces: self._model(inputs, training=False)['image'] (eval/interpolator.py:170-172). */
+int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out,
+                 int mem_kind, void* stream);
+
+/* Execution options.  Keys:
+ *   "graph"   0/1  replay the plan as a hipGraph (default 1)
+ *   "profile" 0/1  record a hipEvent pair around every kernel of the next forwards
+ *                  (forces graph off); read the result with film_profile_json        */
+int film_set_option(film_t* h, const char* key, int64_t value);
+
+/* Per-kernel-class timing of the last profiled forward as JSON
+ * {"classes": {"conv_mfma": {"launches": n, "ms": t, "flops": f, "bytes": b}, ...}}. */
+int film_profile_json(film_t* h, char* buf, int64_t capacity, int64_t* needed);
+
+/* Description of the plan for (B,H,W) as JSON: named workspace buffers (offset, dims),
+ * the op list with every kernel parameter and the packed-weight offsets.  Works on
+ * plan-only handles; tests interpret it against a numpy arena to validate planner and
+ * weight packing without a GPU. */
+int film_plan_json(film_t* h, int B, int H, int W, char* buf, int64_t capacity, int64_t* needed);
+
+/* Copies a named workspace buffer of the last forward (see "buffers" in film_plan_json) to a
+ * host array; dims receives {N,H,W,C}.  Debug / parity taps, mirrors the aux outputs of
+ * models/film_net/interpolator.py:191-199. */
+int film_get_tap(film_t* h, const char* name, float* dst, int64_t capacity_floats, int64_t dims[4]);
+
+/* Library build info: "gfx950;<build id>" */
+const char* film_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FILM_HIP_H_ */

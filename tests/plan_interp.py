@@ -1,0 +1,117 @@
+"""Test-only numpy interpreter of the engine's execution plan (film_plan_json).
+
+The HIP engine plans a forward pass as a list of kernel launches over one workspace arena.  This
+module executes that same op list on a numpy arena, giving every op the semantics its HIP kernel
+implements (frame-interpolation_amd/csrc/*.hip).  It lets the CPU test-suite validate the planner
+(buffer layout, concat-by-slices, batch remaps, upsample folding) and the weight packer
+(channel permutation / zero padding) against the oracle WITHOUT a GPU.  It is test infrastructure:
+nothing under frame-interpolation_amd/ imports it.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from oracle import film_oracle as fo
+
+
+def _view(arena: np.ndarray, v: dict, nb: int, h: int, w: int) -> np.ndarray:
+    s = v['stride']
+    base = arena[v['off']:]
+    need = ((nb * h * w - 1) * s + v['C'])
+    assert need <= base.size, 'view exceeds arena'
+    return np.lib.stride_tricks.as_strided(
+        base, shape=(nb, h, w, v['C']), strides=(h * w * s * 4, w * s * 4, s * 4, 4), writeable=True)
+
+
+def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> np.ndarray:
+    """Executes the plan; returns the arena (use `tap` to read named buffers)."""
+    arena = np.zeros(plan['arena_floats'], dtype=np.float32)
+    bufs = {b['name']: b for b in plan['buffers']}
+    B = plan['B']
+    img0 = bufs['img0']
+    n = x0.size
+    arena[img0['off']:img0['off'] + n] = x0.ravel()
+    arena[img0['off'] + n:img0['off'] + 2 * n] = x1.ravel()
+    for op in plan['ops']:
+        k = op['kind']
+        nb, h, w = op['NB'], op['H'], op['W']
+        if k == 'conv_mfma':
+            parts = []
+            for sg in op['segs']:
+                hs, ws = (h // 2, w // 2) if sg['up'] else (h, w)
+                if sg['bmod']:
+                    src = _view(arena, sg['v'], sg['bmod'], hs, ws)
+                    idx = (np.arange(nb) + sg['boff']) % sg['bmod']
+                    src = src[idx]
+                else:
+                    src = _view(arena, sg['v'], nb, hs, ws)
+                if sg['up']:
+                    src = np.repeat(np.repeat(src, 2, axis=1), 2, axis=2)
+                parts.append(src)
+            x = np.ascontiguousarray(np.concatenate(parts, axis=-1))
+            ks, ct, co = op['ksize'], op['Ctot'], op['Cout']
+            assert x.shape[-1] == ct
+            wt = packed[op['w_off']:op['w_off'] + ks * ks * ct * co].reshape(ks, ks, ct, co)
+            bias = packed[op['b_off']:op['b_off'] + co]
+            y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+            _view(arena, op['out'], nb, h, w)[...] = y
+        elif k == 'conv_c3':
+            x = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
+            co = op['Cout']
+            wt = packed[op['w_off']:op['w_off'] + 27 * co].reshape(3, 3, 3, co)
+            bias = packed[op['b_off']:op['b_off'] + co]
+            _view(arena, op['out'], nb, h, w)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+        elif k == 'conv_pw':
+            m = op['n']
+            x = np.ascontiguousarray(_view(arena, op['in'], 1, 1, m))
+            ci, co = op['Ctot'], op['Cout']
+            wt = packed[op['w_off']:op['w_off'] + ci * co].reshape(1, 1, ci, co)
+            bias = packed[op['b_off']:op['b_off'] + co]
+            _view(arena, op['out'], 1, 1, m)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+        elif k == 'pool':
+            x = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
+            _view(arena, op['out'], nb, h // 2, w // 2)[...] = fo.avg_pool2x2(x)
+        elif k == 'flow_up':
+            x = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
+            _view(arena, op['out'], nb, 2 * h, 2 * w)[...] = fo.resize_bilinear(np.float32(2) * x, (2 * h, 2 * w))
+        elif k == 'flow_add':
+            m = op['n'] // 2
+            a = _view(arena, op['in'], 1, 1, m)
+            b = _view(arena, op['in2'], 1, 1, m)
+            _view(arena, op['out'], 1, 1, m)[...] = a + b
+        elif k == 'warp':
+            src = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
+            flow = np.ascontiguousarray(_view(arena, op['in2'], nb, h, w))
+            _view(arena, op['out'], nb, h, w)[...] = fo.warp(src, np.float32(op['fscale']) * flow)
+        elif k == 'pack_flow':
+            m = op['n']
+            bf = _view(arena, op['in'], 1, 1, m)
+            ff = _view(arena, op['in2'], 1, 1, m)
+            out = _view(arena, op['out'], 1, 1, m)
+            out[..., 0:2] = bf * np.float32(0.5)
+            out[..., 2:4] = ff * np.float32(0.5)
+            out[..., 4:10] = 0
+        else:
+            raise ValueError(k)
+    return arena
+
+
+def tap(plan: dict, arena: np.ndarray, name: str) -> np.ndarray:
+    b = next(x for x in plan['buffers'] if x['name'] == name)
+    return arena[b['off']:b['off'] + b['floats']].reshape(b['N'], b['H'], b['W'], b['C']).copy()
+
+
+# ----------------------------------------------------------------------------------------------
+# Conversions between the engine's internal layouts and the reference's tensors
+# ----------------------------------------------------------------------------------------------
+def split_pair(x: np.ndarray, B: int):
+    """[2B,...] batch (n = s*B + b) -> (first half, second half)."""
+    return x[:B], x[B:]
+
+
+def aligned_to_reference(a: np.ndarray, C: int) -> np.ndarray:
+    """internal [feat0 C | feat1 C | img0 3 | img1 3 | bflow 2 | fflow 2 | 0x6] ->
+    reference [img0 | feat0 | img1 | feat1 | bflow | fflow] (interpolator.py:167-183)."""
+    f0, f1 = a[..., :C], a[..., C:2 * C]
+    m = a[..., 2 * C:]
+    return np.concatenate([m[..., 0:3], f0, m[..., 3:6], f1, m[..., 6:8], m[..., 8:10]], axis=-1)

@@ -1,0 +1,178 @@
+"""GPU parity tests: HIP engine (through the C-ABI) vs the CPU oracle, stage by stage and end to end.
+
+Tolerances (float32): the north_star bound is |delta| < 1e-3 per pixel on the output image; the
+per-stage taps are held to much tighter bounds because the engine uses exact-f32 MFMA (an fmaf chain)
+and differs from the oracle only in summation order.
+"""
+import numpy as np
+import pytest
+
+from conftest import oracle_options
+
+pytestmark = pytest.mark.gpu
+
+IMAGE_TOL = 1e-3     # north_star: |delta| < 1e-3 fp32 per pixel
+FEATURE_TOL = 2e-4   # activations are O(1); K up to ~22k f32 accumulations
+FLOW_TOL = 2e-4      # pixels
+
+
+def _pair(b, h, w, seed):
+    rng = np.random.default_rng(seed)
+    x0 = rng.random((b, h, w, 3), dtype=np.float32)
+    x1 = np.roll(x0, (2, -3), axis=(1, 2)) + rng.normal(0, 0.02, x0.shape).astype(np.float32)
+    return x0, x1.astype(np.float32)
+
+
+def _engine(opt, weights):
+    from film_hip.engine import FilmEngine
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(weights)
+    return eng
+
+
+def _check_stages(eng, opt, weights, x0, x1):
+    from film_hip import weights as W
+    from oracle import film_oracle as fo
+    import plan_interp as pi
+    B = x0.shape[0]
+    got = eng.forward(x0, x1)
+    want, aux = fo.film_forward(x0, x1, weights, oracle_options(opt), return_aux=True)
+    fc = W.feature_channels(opt)
+    report = {}
+    for l in range(opt.pyramid_levels):
+        f = eng.tap(f'feat{l}')
+        report[f'feat{l}'] = max(np.abs(f[:B] - aux['feature_pyramids'][0][l]).max(),
+                                 np.abs(f[B:] - aux['feature_pyramids'][1][l]).max())
+        r = eng.tap(f'res{l}')
+        report[f'res{l}'] = max(np.abs(r[:B] - aux['forward_residual_flow_pyramid'][l]).max(),
+                                np.abs(r[B:] - aux['backward_residual_flow_pyramid'][l]).max())
+    for l in range(opt.fusion_pyramid_levels):
+        v = eng.tap(f'v{l}' if l < opt.pyramid_levels - 1 else f'res{l}')
+        report[f'flow{l}'] = max(np.abs(v[:B] - aux['forward_flow_pyramid'][l]).max(),
+                                 np.abs(v[B:] - aux['backward_flow_pyramid'][l]).max())
+        a = pi.aligned_to_reference(eng.tap(f'aligned{l}'), fc[l])
+        report[f'aligned{l}'] = np.abs(a - aux['aligned_pyramid'][l]).max()
+    report['image'] = np.abs(got - want).max()
+    print({k: float(f'{v:.2e}') for k, v in report.items()})
+    for k, v in report.items():
+        tol = IMAGE_TOL if k == 'image' else FLOW_TOL if k.startswith(('res', 'flow')) else FEATURE_TOL
+        assert v < tol, f'{k}: max|delta| {v} >= {tol}'
+    assert got.shape == want.shape
+    return got, want
+
+
+@pytest.mark.parametrize('b,h,w', [(1, 32, 32), (2, 40, 56), (3, 64, 24)])
+def test_tiny_config_stages(tiny_weights, b, h, w):
+    """Small architecture, ragged sizes (M not a multiple of any tile, B > 1)."""
+    from film_hip.options import TINY
+    eng = _engine(TINY, tiny_weights)
+    x0, x1 = _pair(b, h, w, seed=b * 100 + h)
+    _check_stages(eng, TINY, tiny_weights, x0, x1)
+    eng.close()
+
+
+@pytest.fixture(scope='module')
+def published():
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    eng = _engine(PUBLISHED, w)
+    yield PUBLISHED, w, eng
+    eng.close()
+
+
+def test_published_64(published):
+    opt, w, eng = published
+    x0, x1 = _pair(1, 64, 64, seed=5)
+    _check_stages(eng, opt, w, x0, x1)
+
+
+def test_published_config2_256(published):
+    """BASELINE.json configs[1]: single 256x256 pair, fp32 parity."""
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    x0, x1 = _pair(1, 256, 256, seed=1)
+    got, want = _check_stages(eng, opt, w, x0, x1)
+    assert fo.psnr(got, want) > 80.0
+
+
+def test_published_batch_and_rect(published):
+    opt, w, eng = published
+    x0, x1 = _pair(2, 64, 128, seed=9)
+    _check_stages(eng, opt, w, x0, x1)
+
+
+def test_deterministic_and_graph_equals_eager(published):
+    """No atomics anywhere: two runs are bitwise equal, and hipGraph replay == eager launches."""
+    opt, w, eng = published
+    x0, x1 = _pair(1, 128, 192, seed=3)
+    a = eng.forward(x0, x1)
+    b = eng.forward(x0, x1)
+    eng.set_option('graph', 0)
+    c = eng.forward(x0, x1)
+    eng.set_option('graph', 1)
+    assert np.array_equal(a, b)
+    assert np.array_equal(a, c)
+
+
+def test_batch_equals_single(published):
+    """Batch items are independent: forward on B=2 == two forwards on B=1 (bitwise)."""
+    opt, w, eng = published
+    x0, x1 = _pair(2, 64, 64, seed=11)
+    both = eng.forward(x0, x1)
+    for i in range(2):
+        one = eng.forward(x0[i:i + 1], x1[i:i + 1])
+        assert np.array_equal(both[i:i + 1], one)
+
+
+def test_swap_symmetry(published):
+    """Swapping the inputs swaps forward/backward flows exactly (shared weights, both directions
+    computed by the same launches)."""
+    opt, w, eng = published
+    x0, x1 = _pair(1, 64, 64, seed=13)
+    eng.forward(x0, x1)
+    v01 = eng.tap('v0')
+    eng.forward(x1, x0)
+    v10 = eng.tap('v0')
+    assert np.array_equal(v01[0], v10[1]) and np.array_equal(v01[1], v10[0])
+
+
+def test_interpolator_tiled_matches_oracle_and_patchwise(published):
+    """eval.interpolator.Interpolator: align + block_shape path vs the oracle wrapper, and the batched
+    tiles vs tile-by-tile calls (the reference's loop, eval/interpolator.py:199-202)."""
+    from eval.interpolator import Interpolator, image_to_patches, patches_to_image
+    from oracle import film_oracle as fo
+    opt, w, _ = published
+    x0, x1 = _pair(1, 120, 200, seed=17)   # 2x2 blocks of 60x100 -> padded to 64x128
+    dt = np.full((1,), 0.5, np.float32)
+    it = Interpolator('', align=64, block_shape=[2, 2], weights=w)
+    got = it(x0, x1, dt)
+    want = fo.OracleInterpolator(w, align=64, block_shape=[2, 2])(x0, x1, dt)
+    assert got.shape == (1, 120, 200, 3)
+    assert np.abs(got - want).max() < IMAGE_TOL
+    p0, p1 = image_to_patches(x0, [2, 2]), image_to_patches(x1, [2, 2])
+    one_by_one = np.concatenate([it.interpolate(a[None], b[None], dt) for a, b in zip(p0, p1)], axis=0)
+    assert np.array_equal(patches_to_image(one_by_one, [2, 2]), got)
+
+
+def test_device_path_equals_host_path(published):
+    import torch
+    from film_hip.torch_io import DeviceInterpolator
+    from eval.interpolator import Interpolator
+    opt, w, eng = published
+    x0, x1 = _pair(1, 100, 150, seed=19)
+    it = Interpolator('', align=64, block_shape=[2, 2], weights=w)
+    host = it(x0, x1, np.full((1,), 0.5, np.float32))
+    dev = DeviceInterpolator(eng, align=64, block_shape=[2, 2])(torch.from_numpy(x0).cuda(), torch.from_numpy(x1).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(dev.cpu().numpy(), host)
+
+
+def test_errors(published):
+    from film_hip.engine import FilmError
+    opt, w, eng = published
+    x = np.zeros((1, 100, 64, 3), np.float32)
+    with pytest.raises(FilmError):
+        eng.forward(x, x)  # H not divisible by 64 (options.py:36-37)
+    x = np.zeros((1, 64, 64, 3), np.float32)
+    assert np.isfinite(eng.forward(x, x)).all()
