@@ -68,21 +68,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
   // ---- per-thread B staging ------------------------------------------------------------------
   // float4 index f = t + 256*i -> (krow = f / (BN/4), n4 = f % (BN/4))
+  // Every thread issues its loads unconditionally (a predicated load makes hipcc branch around it and
+  // wait vmcnt(0) right behind it - cdna_hip_programming.md "three .s-level traps" (c)); when the B tile
+  // has fewer than 256 float4 (BN = 32) the upper threads re-read a valid element and skip the LDS store.
+  constexpr bool B_ALL = (BF4 % 256) == 0;
   const float* bbase[BLD];
-  bool bact[BLD];
 #pragma unroll
   for (int i = 0; i < BLD; ++i) {
-    int f = t + 256 * i;
-    bact[i] = f < BF4;
-    int ff = bact[i] ? f : 0;
-    int krow = ff / (BN / 4), n4 = ff % (BN / 4);
+    const int f = (t + 256 * i) % BF4;
+    const int krow = f / (BN / 4), n4 = f % (BN / 4);
     bbase[i] = p.w + (size_t)krow * p.Cout + n0 + n4 * 4;
   }
+  const bool bstore = B_ALL || t < BF4;
 
   // ---- K iteration state ---------------------------------------------------------------------
   int tap = 0, sg = 0, c0 = 0;
   const float* aptr[AROWS];
-  bool ainb[AROWS];
+  bool ainb[AROWS];       // in-image mask of the rows for the CURRENT (tap, segment)
+  bool ainb_prev[AROWS];  // mask that belongs to the data sitting in ra[] (set by load_global's caller)
 
   auto setup_a = [&]() {  // called when (tap, segment) changes
     const int dy = tap / p.ksize - pad, dx = tap % p.ksize - pad;
@@ -101,27 +104,32 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
   };
 
-  float4 ra[AROWS], rb[BLD];
+  static_assert(BLD == 1 || BLD == 2, "B staging holds one or two float4 per thread");
+  float4 ra[AROWS];
+  float4 rb0, rb1;  // named scalars: a 2-element array here is left in scratch memory by hipcc
   int kstep = 0;  // global K-step index == weight row / 16
   auto load_global = [&]() {
+    // out-of-image rows point at a valid pixel (setup_a) and are zeroed when written to LDS
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i) {
-      ra[i] = ainb[i] ? *reinterpret_cast<const float4*>(aptr[i] + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int i = 0; i < BLD; ++i) {
-      if (bact[i]) rb[i] = *reinterpret_cast<const float4*>(bbase[i] + (size_t)kstep * BK * p.Cout);
-    }
+    for (int i = 0; i < AROWS; ++i) ra[i] = *reinterpret_cast<const float4*>(aptr[i] + c0);
+    const size_t koff = (size_t)kstep * BK * p.Cout;
+    rb0 = *reinterpret_cast<const float4*>(bbase[0] + koff);
+    if constexpr (BLD == 2) rb1 = *reinterpret_cast<const float4*>(bbase[BLD - 1] + koff);
   };
   auto store_lds = [&](int buf) {
     float* As = smem + buf * (A_SZ + B_SZ);
     float* Bs = As + A_SZ;
 #pragma unroll
-    for (int i = 0; i < AROWS; ++i)
-      *reinterpret_cast<float4*>(As + (arow + 64 * i) * AST + acol) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BLD; ++i)
-      if (bact[i]) *reinterpret_cast<float4*>(Bs + (t + 256 * i) * 4) = rb[i];
+    for (int i = 0; i < AROWS; ++i) {
+      float4 v = ra[i];
+      v.x = ainb_prev[i] ? v.x : 0.f; v.y = ainb_prev[i] ? v.y : 0.f;
+      v.z = ainb_prev[i] ? v.z : 0.f; v.w = ainb_prev[i] ? v.w : 0.f;
+      *reinterpret_cast<float4*>(As + (arow + 64 * i) * AST + acol) = v;
+    }
+    if (bstore) {
+      *reinterpret_cast<float4*>(Bs + (t % BF4) * 4) = rb0;
+      if constexpr (BLD == 2) *reinterpret_cast<float4*>(Bs + (t + 256) * 4) = rb1;
+    }
   };
   auto advance = [&]() {
     ++kstep;
@@ -145,33 +153,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 
   setup_a();
   load_global();
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) ainb_prev[i] = ainb[i];
   store_lds(0);
   __syncthreads();
 
   int cur = 0;
   for (int s = 0; s < nsteps; ++s) {
     const bool more = s + 1 < nsteps;
-    if (more) { advance(); load_global(); }
+    if (more) {
+      advance();
+      load_global();
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) ainb_prev[i] = ainb[i];
+    }
 
     const float* As = smem + cur * (A_SZ + B_SZ);
     const float* Bs = As + A_SZ;
+    // all fragment reads of the step first (16 K-values: 2 x ds_read_b128 per M tile, 8 x ds_read_b32
+    // per N tile), then the 8*TM*TN MFMAs: the compiler retires the reads with counted lgkmcnt waits
+    // while the matrix pipe is already busy.
+    float4 a[2][TM];
+    float b[2][4][TN];
 #pragma unroll
-    for (int kq = 0; kq < 2; ++kq) {
-      float4 a[TM];
+    for (int kq = 0; kq < 2; ++kq)
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
-        a[mt] = *reinterpret_cast<const float4*>(As + (wm * WTM + mt * 32 + l31) * AST + kq * 8 + half * 4);
+        a[kq][mt] = *reinterpret_cast<const float4*>(As + (wm * WTM + mt * 32 + l31) * AST + kq * 8 + half * 4);
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt) b[kq][j][nt] = Bs[(kq * 8 + half * 4 + j) * BN + wn * WTN + nt * 32 + l31];
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float b[TN];
-#pragma unroll
-        for (int nt = 0; nt < TN; ++nt) b[nt] = Bs[(kq * 8 + half * 4 + j) * BN + wn * WTN + nt * 32 + l31];
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
-          const float av = j == 0 ? a[mt].x : j == 1 ? a[mt].y : j == 2 ? a[mt].z : a[mt].w;
+          const float av = j == 0 ? a[kq][mt].x : j == 1 ? a[kq][mt].y : j == 2 ? a[kq][mt].z : a[kq][mt].w;
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kq][j][nt], acc[mt][nt], 0, 0, 0);
         }
       }
     }
@@ -219,6 +243,8 @@ hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
     case TILE_256x32: return launch<256, 32, 4, 1>(p, s);
     case TILE_64x64: return launch<64, 64, 2, 2>(p, s);
     case TILE_128x32: return launch<128, 32, 4, 1>(p, s);
+    case TILE_128x64: return launch<128, 64, 2, 2>(p, s);
+    case TILE_256x128: return launch<256, 128, 4, 1>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -120,8 +120,9 @@ struct film_handle {
   std::vector<std::unique_ptr<Plan>> plans;
   Plan* last_plan = nullptr;
   uint64_t tick = 0;
-  int opt_graph = 1, opt_profile = 0;
+  int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   std::string profile_json;
+  std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
 };
 
 namespace {
@@ -352,11 +353,14 @@ struct Planner {
     op.bytes = 4.0 * NB * H * W * in.C * 1.25;
     P->ops.push_back(op);
   }
-  void warp(const std::string& tag, View src, View flow, View dst, int NB, int H, int W, float fscale) {
+  void warp(const std::string& tag, View src, View flow, View dst, int NB, int H, int W, float fscale,
+            bool count_flow = true) {
     OpDesc op;
     op.kind = OP_WARP; op.tag = tag; op.in = src; op.in2 = flow; op.out = dst;
     op.NB = NB; op.H = H; op.W = W; op.fscale = fscale;
-    op.bytes = 4.0 * NB * H * W * (2.0 * src.C + 2);  // read source once + flow, write once
+    // read source once + flow, write once.  The image part of a [image|features] warp is
+    // a second launch here; its re-read of the flow is not algorithmic traffic.
+    op.bytes = 4.0 * NB * H * W * (2.0 * src.C + (count_flow ? 2 : 0));
     P->ops.push_back(op);
   }
 
@@ -495,7 +499,7 @@ struct Planner {
         warp(tg + ":warp_feat" + std::to_string(s), view(feat[l], s * B, 0, fc[l]), fl,
              view(aligned[l], 0, s * fc[l], fc[l]), B, HL(l), WL(l), 0.5f);
         warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
-             view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f);
+             view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f, false);
       }
       OpDesc pk;
       pk.kind = OP_PACK_FLOW; pk.tag = tg + ":flows";
@@ -598,6 +602,68 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
   return hipErrorInvalidValue;
 }
 
+std::vector<int> tile_candidates(int Cout) {
+  if (Cout % 128 == 0) return {TILE_128x128, TILE_256x128, TILE_256x64, TILE_128x64, TILE_64x64};
+  if (Cout % 64 == 0) return {TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_128x32};
+  return {TILE_256x32, TILE_128x32};
+}
+
+std::string conv_signature(const OpDesc& op) {
+  std::ostringstream o;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride;
+  for (int i = 0; i < op.nseg; ++i)
+    o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
+  return o.str();
+}
+
+hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream_t s);
+
+// Measure, don't guess: every distinct conv shape of a plan is timed once with each tile shape that fits
+// its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
+// results: every output element is the same k-ordered fma chain whatever the tile.
+int autotune_plan(film_t* h, Plan* P) {
+  bool need = false;
+  for (const OpDesc& op : P->ops)
+    if (op.kind == OP_CONV && !h->tune_cache.count(conv_signature(op))) need = true;
+  if (need) {
+    HIPCHK(h, film_launch_fill_random(P->arena, P->arena_floats, 0x9e3779b9u, h->stream));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    for (OpDesc& op : P->ops) {
+      if (op.kind != OP_CONV) continue;
+      const std::string sig = conv_signature(op);
+      if (h->tune_cache.count(sig)) continue;
+      int best = op.tile;
+      float best_ms = 1e30f;
+      for (int tile : tile_candidates(op.Cout)) {
+        OpDesc trial = op;
+        trial.tile = tile;
+        HIPCHK(h, launch_op(trial, P->arena, h->packed_dev, h->stream));  // warm
+        float ms_min = 1e30f;
+        for (int rep = 0; rep < 2; ++rep) {
+          HIPCHK(h, hipEventRecord(e0, h->stream));
+          HIPCHK(h, launch_op(trial, P->arena, h->packed_dev, h->stream));
+          HIPCHK(h, hipEventRecord(e1, h->stream));
+          HIPCHK(h, hipEventSynchronize(e1));
+          float ms = 0;
+          HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+          ms_min = std::min(ms_min, ms);
+        }
+        if (ms_min < best_ms) { best_ms = ms_min; best = tile; }
+      }
+      h->tune_cache[sig] = best;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    HIPCHK(h, hipMemsetAsync(P->arena, 0, (size_t)P->arena_floats * sizeof(float), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+  }
+  for (OpDesc& op : P->ops)
+    if (op.kind == OP_CONV) op.tile = h->tune_cache.at(conv_signature(op));
+  return FILM_OK;
+}
+
 void free_plan(Plan* p) {
   if (!p) return;
   if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
@@ -644,6 +710,10 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
     }
     HIPCHK(h, hipMemsetAsync(P->arena, 0, (size_t)P->arena_floats * sizeof(float), h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->opt_autotune && h->finalized) {
+      int trc = autotune_plan(h, P.get());
+      if (trc) { free_plan(P.get()); return trc; }
+    }
   }
   P->last_use = ++h->tick;
   *out = P.get();
@@ -862,6 +932,7 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   if (!h || !key) return FILM_ERR_INVALID;
   if (!strcmp(key, "graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
+  else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else return fail(h, FILM_ERR_NOTFOUND, "unknown option '%s'", key);
   return FILM_OK;
 }

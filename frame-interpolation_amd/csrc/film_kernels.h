@@ -111,7 +111,7 @@ struct PackFlowParams {
 };
 
 enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
-                TILE_COUNT = 5 };
+                TILE_128x64 = 5, TILE_256x128 = 6, TILE_COUNT = 7 };
 
 struct TileShape { int bm, bn; };
 static inline TileShape film_tile_shape(int tile) {
@@ -120,6 +120,8 @@ static inline TileShape film_tile_shape(int tile) {
     case TILE_256x64: return {256, 64};
     case TILE_256x32: return {256, 32};
     case TILE_64x64: return {64, 64};
+    case TILE_128x64: return {128, 64};
+    case TILE_256x128: return {256, 128};
     default: return {128, 32};
   }
 }
@@ -132,3 +134,5 @@ hipError_t film_launch_flow_up(const FlowUpParams& p, hipStream_t s);
 hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s);
 hipError_t film_launch_warp(const WarpParams& p, hipStream_t s);
 hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s);
+// fills n floats with a deterministic pseudo-random pattern in [-1, 1) (autotune inputs only)
+hipError_t film_launch_fill_random(float* dst, int64_t n, uint32_t seed, hipStream_t s);

@@ -271,6 +271,16 @@ __global__ __launch_bounds__(256) void pack_flow_kernel(PackFlowParams p) {
   for (int i = 4; i < 10; ++i) d[i] = 0.f;
 }
 
+__global__ __launch_bounds__(256) void fill_random_kernel(float* dst, int64_t n, uint32_t seed) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    uint32_t x = (uint32_t)i * 2654435761u ^ seed ^ (uint32_t)(i >> 32) * 40503u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    dst[i] = (float)(int32_t)x * (1.0f / 2147483648.0f);
+  }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -326,5 +336,10 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
 
 hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s) {
   hipLaunchKernelGGL(pack_flow_kernel, dim3(blocks_for(p.npix)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t film_launch_fill_random(float* dst, int64_t n, uint32_t seed, hipStream_t s) {
+  hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, s, dst, n, seed);
   return hipGetLastError();
 }

@@ -44,7 +44,23 @@ def build(force: bool = False, verbose: bool = True) -> str:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
     if force or procs or _stale(OUT, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs
+        # ONE HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (no SONAME,
+        # its libraries NEED the unversioned name "libamdhip64.so"); linking against
+        # /opt/rocm/lib/libamdhip64.so would record the SONAME "libamdhip64.so.7", which glibc does not
+        # match with torch's copy -> two runtimes in one process (the second one sees no GPU, and
+        # streams / pointers cross runtimes).  So the final link is done by g++ against an empty,
+        # SONAME-less stub: DT_NEEDED becomes "libamdhip64.so", which resolves to whichever runtime is
+        # already loaded (torch's, when torch was imported first) or to /opt/rocm/lib via RUNPATH.
+        stub_dir = os.path.join(bdir, 'stub')
+        os.makedirs(stub_dir, exist_ok=True)
+        stub_c = os.path.join(stub_dir, 'empty.c')
+        with open(stub_c, 'w') as f:
+            f.write('/* link-time stub: gives libfilm_hip.so a DT_NEEDED of "libamdhip64.so" */\n')
+        subprocess.check_call(['gcc', '-shared', '-fPIC', '-o', os.path.join(stub_dir, 'libamdhip64.so'), stub_c])
+        rocm_lib = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib')
+        cmd = ['g++', '-shared', '-fPIC', '-o', OUT] + objs + [
+            '-L' + stub_dir, '-Wl,--no-as-needed', '-lamdhip64', '-Wl,--as-needed',
+            '-Wl,-rpath,' + rocm_lib, '-Wl,--enable-new-dtags']
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd, cwd=CSRC)

@@ -58,6 +58,14 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         raise FileNotFoundError(
             f'{p} not found: build the HIP engine first (python -c "import __graft_entry__ as g; g.build()" '
             'or make -C frame-interpolation_amd/csrc). There is no CPU fallback.')
+    try:
+        # PyTorch-ROCm bundles its own HIP runtime; importing it first makes libfilm_hip.so (whose
+        # DT_NEEDED is the unversioned "libamdhip64.so", see film_hip/build.py) bind to that same
+        # runtime, so device pointers and streams can be exchanged with torch.  Without torch the
+        # system runtime under /opt/rocm/lib is used.
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover
+        pass
     lib = ctypes.CDLL(p)
     vp, cp, i64p, fp = ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p
     lib.film_default_config.argtypes = [ctypes.POINTER(_Config)]

@@ -99,6 +99,8 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
                  int mem_kind, void* stream);
 
 /* Execution options.  Keys:
+ *   "autotune" 0/1 time every distinct conv shape of a new plan with each fitting tile shape and keep
+ *                  the fastest (default 1; cannot change results - same k-ordered fma chain per output)
  *   "graph"   0/1  replay the plan as a hipGraph (default 1)
  *   "profile" 0/1  record a hipEvent pair around every kernel of the next forwards
  *                  (forces graph off); read the result with film_profile_json        */

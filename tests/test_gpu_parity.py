@@ -176,3 +176,41 @@ def test_errors(published):
         eng.forward(x, x)  # H not divisible by 64 (options.py:36-37)
     x = np.zeros((1, 64, 64, 3), np.float32)
     assert np.isfinite(eng.forward(x, x)).all()
+
+
+def test_tiny_matches_committed_golden(tiny_weights):
+    """HIP engine vs the committed fixture tests/golden/tiny_golden.npz (generated by the oracle; provenance in
+    tests/golden/make_golden.py)."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    from film_hip.options import TINY
+    spec = importlib.util.spec_from_file_location('make_golden', os.path.join(ROOT, 'tests', 'golden', 'make_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(ROOT, 'tests', 'golden', 'tiny_golden.npz'))
+    x0, x1 = mg.inputs()
+    eng = _engine(TINY, tiny_weights)
+    got = eng.forward(x0, x1)
+    B = x0.shape[0]
+    v0 = eng.tap('v0')
+    assert np.abs(got - g['image']).max() < IMAGE_TOL
+    assert np.abs(got - g['image_f64']).max() < IMAGE_TOL          # and vs the float64 evaluation
+    assert np.abs(v0[:B] - g['forward_flow0']).max() < FLOW_TOL
+    assert np.abs(v0[B:] - g['backward_flow0']).max() < FLOW_TOL
+    assert np.abs(eng.tap('feat2')[:B] - g['feat2_img0']).max() < FEATURE_TOL
+    eng.close()
+
+
+def test_autotuned_tiles_do_not_change_results(published):
+    """Whatever tile shape the autotuner picks, every output is the same k-ordered fma chain."""
+    from film_hip.engine import FilmEngine
+    opt, w, eng = published
+    x0, x1 = _pair(1, 64, 192, seed=23)
+    tuned = eng.forward(x0, x1)
+    plain = FilmEngine(opt, device=0)
+    plain.set_option('autotune', 0)
+    plain.set_weights(w)
+    ref = plain.forward(x0, x1)
+    plain.close()
+    assert np.array_equal(tuned, ref)

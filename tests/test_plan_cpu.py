@@ -1,0 +1,181 @@
+"""CPU tests of the native library WITHOUT a GPU: symbol export, weight packing, the planner.
+
+The op list the engine would launch (film_plan_json) is executed by the numpy interpreter in
+tests/plan_interp.py and compared with the oracle: this validates buffer layout, concat-by-slices,
+batch remaps, the folded NN-upsample and the weight permutation/zero padding on the CPU.  No compute
+happens inside libfilm_hip.so in these tests (plan-only handles refuse to).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import oracle_options, ROOT
+
+
+def test_library_exports_every_declared_symbol():
+    from film_hip import engine
+    lib = engine.load_library()
+    header = open(os.path.join(ROOT, 'include', 'film_hip.h')).read()
+    declared = set(re.findall(r'^(?:int|void|const char\*)\s+(film_[a-z_0-9]+)\s*\(', header, flags=re.M))
+    assert declared == set(engine.EXPORTED_SYMBOLS), declared ^ set(engine.EXPORTED_SYMBOLS)
+    for sym in declared:
+        assert getattr(lib, sym) is not None
+    assert engine.FilmEngine.version().startswith('gfx950')
+
+
+def test_no_cpu_fallback_without_device():
+    """The product path must fail loudly without a GPU (no silent CPU/eager fallback)."""
+    import torch
+    from film_hip.engine import FilmEngine, FilmError, FILM_ERR_NO_DEVICE
+    from film_hip.options import TINY
+    eng = FilmEngine(TINY, device=-1)
+    x = np.zeros((1, 32, 32, 3), np.float32)
+    with pytest.raises(FilmError) as e:
+        eng.forward(x, x)
+    assert e.value.code in (FILM_ERR_NO_DEVICE, -2)
+    if not torch.cuda.is_available():
+        with pytest.raises(FilmError) as e2:
+            FilmEngine(TINY, device=0)
+        assert e2.value.code == FILM_ERR_NO_DEVICE
+        from eval.interpolator import Interpolator
+        from film_hip import weights as W
+        with pytest.raises(FilmError):
+            Interpolator('', weights=W.make_synthetic_weights(TINY, 0), options=TINY)
+
+
+def test_default_config_is_published_architecture():
+    from film_hip import engine
+    lib = engine.load_library()
+    c = engine._Config()
+    assert lib.film_default_config(ctypes.byref(c)) == 0
+    assert (c.pyramid_levels, c.fusion_pyramid_levels, c.specialized_levels, c.sub_levels, c.filters) == (7, 5, 3, 4, 64)
+    assert list(c.flow_convs)[:4] == [3, 3, 3, 3] and list(c.flow_filters)[:4] == [32, 64, 128, 256]
+
+
+def test_weight_table_matches_survey():
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    assert W.num_params(PUBLISHED) == 34436667
+    assert W.feature_channels(PUBLISHED) == [64, 192, 448, 960, 960, 960, 960]
+    specs = {n: s for n, s, _ in W.weight_specs(PUBLISHED)}
+    assert specs['predict_flow/flow_predictor_shared/conv_0'] == (3, 3, 1920, 256)
+    assert specs['fusion/convs_3_0'] == (2, 2, 1930, 512)
+    assert specs['fusion/convs_3_1'] == (3, 3, 2442, 512)
+    assert specs['fusion/output_conv'] == (1, 1, 64, 3)
+
+
+def test_set_weight_validation(tiny_weights):
+    from film_hip.engine import FilmEngine, FilmError
+    from film_hip.options import TINY
+    eng = FilmEngine(TINY, device=-1)
+    with pytest.raises(FilmError):
+        eng.set_weights({'nope/kernel': np.zeros((1, 1, 1, 1), np.float32)})
+    with pytest.raises(FilmError):
+        eng.set_weights({'fusion/output_conv/kernel': np.zeros((1, 1, 5, 3), np.float32)})
+    with pytest.raises(FilmError):   # finalize with tensors missing
+        eng.set_weights({'fusion/output_conv/bias': np.zeros((3,), np.float32)})
+    eng.set_weights(tiny_weights)
+    blob = eng.export_packed()
+    eng2 = FilmEngine(TINY, device=-1)
+    eng2.import_packed(blob)
+    assert np.array_equal(eng2.export_packed(), blob)
+
+
+def test_packing_permutes_fusion_inputs(tiny_weights):
+    """fusion/convs_i_1 rows: internal [feat0|feat1|img0 img1 bflow fflow 0x6|net] <- reference order."""
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    eng = FilmEngine(TINY, device=-1)
+    eng.set_weights(tiny_weights)
+    blob = eng.export_packed()
+    plan = eng.plan(1, 32, 32)
+    L = {l['name']: l for l in plan['layers']}['fusion/convs_0_1']
+    C = W.feature_channels(TINY)[0]
+    ref = tiny_weights['fusion/convs_0_1/kernel']
+    packed = blob[L['w_off']:L['w_off'] + 9 * L['ctot'] * L['cout']].reshape(3, 3, L['ctot'], L['cout'])
+    assert L['ctot'] == 2 * C + 16 + L['cout']
+    assert np.array_equal(packed[:, :, :C], ref[:, :, 3:3 + C])                       # feat0
+    assert np.array_equal(packed[:, :, C:2 * C], ref[:, :, 6 + C:6 + 2 * C])           # feat1
+    assert np.array_equal(packed[:, :, 2 * C:2 * C + 3], ref[:, :, 0:3])               # img0
+    assert np.array_equal(packed[:, :, 2 * C + 3:2 * C + 6], ref[:, :, 3 + C:6 + C])   # img1
+    assert np.array_equal(packed[:, :, 2 * C + 6:2 * C + 10], ref[:, :, 6 + 2 * C:10 + 2 * C])  # flows
+    assert not packed[:, :, 2 * C + 10:2 * C + 16].any()                               # zero rows
+    assert np.array_equal(packed[:, :, 2 * C + 16:], ref[:, :, 10 + 2 * C:])           # net
+
+
+@pytest.mark.parametrize('b,h,w', [(1, 32, 32), (2, 32, 48), (1, 64, 40)])
+def test_plan_interpreter_matches_oracle_tiny(tiny_weights, b, h, w):
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    from oracle import film_oracle as fo
+    import plan_interp as pi
+    eng = FilmEngine(TINY, device=-1)
+    eng.set_weights(tiny_weights)
+    plan = eng.plan(b, h, w)
+    rng = np.random.default_rng(h * 7 + w)
+    x0 = rng.random((b, h, w, 3), dtype=np.float32)
+    x1 = rng.random((b, h, w, 3), dtype=np.float32)
+    arena = pi.run_plan(plan, eng.export_packed(), x0, x1)
+    want, aux = fo.film_forward(x0, x1, tiny_weights, oracle_options(TINY), return_aux=True)
+    fc = W.feature_channels(TINY)
+    for l in range(TINY.pyramid_levels):
+        f = pi.tap(plan, arena, f'feat{l}')
+        assert np.abs(f[:b] - aux['feature_pyramids'][0][l]).max() < 1e-5
+        assert np.abs(f[b:] - aux['feature_pyramids'][1][l]).max() < 1e-5
+        r = pi.tap(plan, arena, f'res{l}')
+        assert np.abs(r[:b] - aux['forward_residual_flow_pyramid'][l]).max() < 1e-5
+        assert np.abs(r[b:] - aux['backward_residual_flow_pyramid'][l]).max() < 1e-5
+    for l in range(TINY.fusion_pyramid_levels):
+        a = pi.aligned_to_reference(pi.tap(plan, arena, f'aligned{l}'), fc[l])
+        assert np.abs(a - aux['aligned_pyramid'][l]).max() < 1e-5
+    assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 1e-5
+
+
+def test_plan_interpreter_matches_oracle_published_64():
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED
+    from oracle import film_oracle as fo
+    import plan_interp as pi
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    eng = FilmEngine(PUBLISHED, device=-1)
+    eng.set_weights(w)
+    plan = eng.plan(1, 64, 64)
+    rng = np.random.default_rng(3)
+    x0 = rng.random((1, 64, 64, 3), dtype=np.float32)
+    x1 = rng.random((1, 64, 64, 3), dtype=np.float32)
+    arena = pi.run_plan(plan, eng.export_packed(), x0, x1)
+    want = fo.film_forward(x0, x1, w, fo.Options())
+    assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
+    # algorithmic conv FLOPs of the plan == SURVEY.md 8(d): 4 246 240.6875 FLOP per padded pixel
+    flops = sum(op['flops'] for op in plan['ops'] if op['kind'].startswith('conv'))
+    assert abs(flops / (64 * 64) - 4246240.6875) / 4246240.6875 < 1e-5
+    warp_bytes = sum(op['bytes'] for op in plan['ops'] if op['kind'] == 'warp')
+    assert abs(warp_bytes / (64 * 64) - 5201.58) / 5201.58 < 1e-3
+
+
+def test_plan_shape_errors(tiny_weights):
+    from film_hip.engine import FilmEngine, FilmError, FILM_ERR_INVALID
+    from film_hip.options import TINY
+    eng = FilmEngine(TINY, device=-1)
+    eng.set_weights(tiny_weights)
+    with pytest.raises(FilmError) as e:
+        eng.plan(1, 36, 32)          # not divisible by 2^(pyramid_levels-1) = 8 (options.py:36-37)
+    assert e.value.code == FILM_ERR_INVALID and 'divisible' in e.value.msg
+    with pytest.raises(FilmError):
+        eng.plan(1, 8, 4)            # a warped level would be < 2x2 (tfa dense_image_warp requirement)
+    with pytest.raises(FilmError):
+        eng.plan(0, 32, 32)
+
+
+def test_invalid_options_rejected():
+    from film_hip.options import Options
+    with pytest.raises(ValueError):
+        Options(pyramid_levels=3, fusion_pyramid_levels=5).validate()   # interpolator.py:120-122
+    with pytest.raises(ValueError):
+        Options(filters=20).validate()
