@@ -960,7 +960,10 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
   Plan* P = nullptr;
   int rc = get_plan(h, B, H, W, true, &P);
   if (rc) return rc;
-  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  // stream == NULL: host buffers -> the handle's own (non-blocking) stream, synchronised before returning;
+  // device buffers -> the NULL (legacy default) stream, i.e. ordered with the caller's default-stream work
+  // (torch's default stream IS the NULL stream, and its handle is 0).
+  hipStream_t s = stream ? (hipStream_t)stream : (mem_kind == FILM_MEM_DEVICE ? (hipStream_t) nullptr : h->stream);
   const size_t in_bytes = (size_t)B * H * W * 3 * sizeof(float);
   const hipMemcpyKind kin = mem_kind == FILM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
   const hipMemcpyKind kout = mem_kind == FILM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;

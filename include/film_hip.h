@@ -91,9 +91,10 @@ int film_import_packed(film_t* h, const float* src, int64_t n_floats, int mem_ki
 /* Runs film_net on B frame pairs: x0, x1 [B,H,W,3] -> out [B,H,W,3] (un-clipped), t = 0.5.
  * H and W must be divisible by 2^(pyramid_levels-1) (options.py:36-37) - pad first, as
  * Interpolator.interpolate does (eval/interpolator.py:166-168).
- * `stream`: a hipStream_t to run on, or NULL for the handle's own stream.  With
- * FILM_MEM_HOST the call synchronises before returning; with FILM_MEM_DEVICE it is
- * asynchronous on the stream.
+ * `stream`: a hipStream_t to run on.  NULL means: with FILM_MEM_HOST the handle's own stream (the call
+ * synchronises before returning); with FILM_MEM_DEVICE the NULL (legacy default) stream, so the work
+ * is ordered with the caller's default-stream work (PyTorch's default stream is the NULL stream) and
+ * the call is asynchronous.
  * Replaces: self._model(inputs, training=False)['image'] (eval/interpolator.py:170-172). */
 int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out,
                  int mem_kind, void* stream);

@@ -1,0 +1,61 @@
+#!/usr/bin/env python
+"""Summarises a rocprofv3 run of bench.py (rocpd sqlite .db from `rocprofv3 --kernel-trace --stats`, or the
+PMC variant) into the markdown tables committed under profiles/.
+
+  python tools/rocprof_summary.py gpurun_out/rocprof/bench_results.db --forwards 5 > profiles/r01_kernel_stats.md
+
+Only the steady-state forwards are counted: the engine autotunes tile shapes when a plan is created, which
+launches every candidate once; those trial launches are excluded by keeping the LAST `forwards` x
+(launches per forward) dispatches of the engine's kernels."""
+import argparse
+import re
+import sqlite3
+import sys
+from collections import defaultdict
+
+ENGINE = re.compile(r'conv_igemm_kernel|conv_c3_kernel|conv_pw_kernel|warp_vec_kernel|warp_c3_kernel|pool_vec_kernel|'
+                    r'pool_c3_kernel|flow_up_kernel|flow_add_kernel|pack_flow_kernel')
+
+
+def short(name):
+    name = name.replace('void (anonymous namespace)::', '').replace('(anonymous namespace)::', '')
+    return re.sub(r'\(.*\)$', '', name)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('db')
+    ap.add_argument('--forwards', type=int, required=True, help='forward passes in the run (warmup + steps + 1 profiled)')
+    ap.add_argument('--launches-per-forward', type=int, default=0, help='0 = infer from pack_flow/conv_pw<3> counts')
+    args = ap.parse_args()
+    db = sqlite3.connect(args.db)
+    cur = db.cursor()
+    rows = [(n, s, e) for n, s, e in cur.execute('select name, start, end from kernels order by start') if ENGINE.search(n)]
+    # conv_pw<3> (the RGB head) runs exactly once per forward and never in autotune
+    heads = [i for i, r in enumerate(rows) if 'conv_pw_kernel<3>' in r[0]]
+    if len(heads) < args.forwards:
+        sys.exit(f'found {len(heads)} forwards, expected {args.forwards}')
+    per_fwd = args.launches_per_forward or (heads[-1] - heads[-2])
+    first = heads[-args.forwards] - per_fwd + 1
+    steady = rows[first:heads[-1] + 1]
+    agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+    for n, s, e in steady:
+        a = agg[short(n)]
+        d = (e - s) / 1e3
+        a[0] += 1; a[1] += d; a[2] = min(a[2], d); a[3] = max(a[3], d)
+    total = sum(a[1] for a in agg.values())
+    print(f'steady-state forwards: {args.forwards}, launches per forward: {per_fwd}, kernel time per forward: '
+          f'{total / args.forwards / 1e3:.3f} ms\n')
+    print('| kernel | calls/forward | total ms/forward | avg us | min us | max us | % |')
+    print('|---|---|---|---|---|---|---|')
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f'| `{k}` | {a[0] / args.forwards:.1f} | {a[1] / args.forwards / 1e3:.3f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | '
+              f'{a[3]:.1f} | {100 * a[1] / total:.2f} |')
+    conv = sum(a[1] for k, a in agg.items() if k.startswith('conv_igemm'))
+    nconv = sum(a[0] for k, a in agg.items() if k.startswith('conv_igemm'))
+    print(f'\nconv_igemm_kernel (all tile shapes): {nconv / args.forwards:.0f} launches/forward, '
+          f'{conv / args.forwards / 1e3:.3f} ms/forward, average launch {conv / nconv:.1f} us')
+
+
+if __name__ == '__main__':
+    main()
