@@ -185,10 +185,19 @@ def main():
         # conv_mfma launches carry all conv FLOPs except the Cin=3 first layer and the tiny 1x1 heads
         conv_tflops = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
         total_ms = sum(c['ms'] for c in cls.values())
+        traffic = None
+        try:  # HBM-side bytes per conv launch from the committed PMC passes of this build (profiles/)
+            import glob
+            pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_conv.json')))
+            if pmc_files and args.workload == '1080p_2x2':
+                traffic = round(json.load(open(pmc_files[-1]))['hbm_bytes_per_launch'])
+        except Exception:
+            traffic = None
         roofline = {
             'bound': 'mfma', 'kernel': 'conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)',
             'achieved': round(conv_tflops, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+            'frac': round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            'traffic_note': 'bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 PMC passes' if traffic else None,
             'launches_per_step': conv['launches'],
             'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
             'class_ms_per_step': round(conv['ms'], 3),
