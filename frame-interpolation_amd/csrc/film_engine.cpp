@@ -31,8 +31,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-enum OpKind { OP_CONV = 0, OP_CONV_C3, OP_CONV_PW, OP_POOL, OP_FLOW_UP, OP_FLOW_ADD, OP_WARP, OP_PACK_FLOW, OP_KINDS };
-const char* kKindName[OP_KINDS] = {"conv_mfma", "conv_c3", "conv_pw", "pool", "flow_up", "flow_add", "warp", "pack_flow"};
+enum OpKind { OP_CONV = 0, OP_FLOW_HEAD, OP_CONV_PW, OP_POOL, OP_FLOW_UP, OP_FLOW_ADD, OP_WARP, OP_PACK_FLOW, OP_KINDS };
+const char* kKindName[OP_KINDS] = {"conv_mfma", "flow_head", "conv_pw", "pool", "flow_up", "flow_add", "warp", "pack_flow"};
 
 struct Buffer {
   std::string name;
@@ -62,7 +62,9 @@ struct OpDesc {
   SegDesc seg[FILM_MAX_SEG];
   int nseg = 0;
   int ksize = 1, leaky = 0, Cout = 0, Ctot = 0, tile = 0;
+  int c3 = 0;                         // first-layer mode of the conv kernel (3-channel image input)
   int64_t w_off = 0, b_off = 0;
+  int64_t w2_off = 0, b2_off = 0;     // flow_head: second 1x1 conv
   // generic views
   View in, in2, out;
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
@@ -76,8 +78,10 @@ struct LayerPack {
   std::string name;
   int kh, kw, cin, cout;     // reference shape
   std::vector<int> perm;     // internal input channel -> reference input channel, -1 = zero row
+  bool c3 = false;           // first layer: packed as [12 tap slots][4][Cout] (row = tap*4 + channel, rest zero)
   int64_t w_off = 0, b_off = 0;
   int ctot() const { return (int)perm.size(); }
+  int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
 };
 
 struct HostTensor {
@@ -227,6 +231,7 @@ void build_layers(film_t* h) {
   for (int i = 0; i < c.sub_levels; ++i) {
     int k = c.filters << i;
     add("feat_net/sub_extractor/cfeat_conv_" + std::to_string(2 * i), 3, 3, cin, k, identity_perm(cin));
+    if (i == 0) h->layers.back().c3 = true;
     add("feat_net/sub_extractor/cfeat_conv_" + std::to_string(2 * i + 1), 3, 3, k, k, identity_perm(k));
     cin = k;
   }
@@ -260,7 +265,7 @@ void build_layers(film_t* h) {
   int64_t off = 0;
   for (auto& L : h->layers) {
     L.w_off = off;
-    off += (int64_t)L.kh * L.kw * L.ctot() * L.cout;
+    off += L.packed_rows() * L.cout;
     off = (off + 3) & ~int64_t(3);
     L.b_off = off;
     off += L.cout;
@@ -311,9 +316,11 @@ struct Planner {
 
   static int choose_tile(int64_t M, int Cout) {
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * (Cout / bn); };
-    if (Cout % 128 == 0) return blocks(128, 128) >= 256 ? TILE_128x128 : TILE_64x64;
-    if (Cout % 64 == 0) return blocks(256, 64) >= 256 ? TILE_256x64 : TILE_64x64;
-    return blocks(256, 32) >= 256 ? TILE_256x32 : TILE_128x32;
+    int shape;
+    if (Cout % 128 == 0) shape = blocks(128, 128) >= 768 ? TILE_128x128 : TILE_64x64;
+    else if (Cout % 64 == 0) shape = blocks(256, 64) >= 768 ? TILE_256x64 : TILE_64x64;
+    else shape = blocks(256, 32) >= 768 ? TILE_256x32 : TILE_128x32;
+    return shape | CONV_TILE_XCD;
   }
 
   void conv(const std::string& tag, const std::string& layer, std::vector<SegDesc> segs, View out, int NB, int H,
@@ -426,9 +433,12 @@ struct Planner {
         if (j == 0) {
           const LayerPack& Lp = h->layers[h->layer_idx.at(w0)];
           OpDesc op;
-          op.kind = OP_CONV_C3; op.tag = tg + ":" + w0;
-          op.in = view(img[i], 0, 0, 3); op.out = tmp; op.NB = N2; op.H = HL(lv); op.W = WL(lv);
-          op.Cout = k; op.leaky = 1; op.w_off = Lp.w_off; op.b_off = Lp.b_off;
+          op.kind = OP_CONV; op.c3 = 1; op.tag = tg + ":" + w0;
+          op.nseg = 1; op.seg[0].v = view(img[i], 0, 0, 3);
+          op.ksize = 3; op.leaky = 1; op.Cout = k; op.Ctot = 3;
+          op.w_off = Lp.w_off; op.b_off = Lp.b_off;
+          op.out = tmp; op.NB = N2; op.H = HL(lv); op.W = WL(lv);
+          op.tile = (k % 64 == 0 ? TILE_256x64 : TILE_256x32) | CONV_TILE_XCD | CONV_TILE_C3;
           op.flops = 2.0 * N2 * HL(lv) * WL(lv) * k * 27; op.bytes = 4.0 * N2 * HL(lv) * WL(lv) * (3 + k);
           P->ops.push_back(op);
         } else {
@@ -477,9 +487,20 @@ struct Planner {
       }
       View hid = scratch(fp[2], nf / 2);
       const std::string l3 = prefix + "/conv_" + std::to_string(nconv), l4 = prefix + "/conv_" + std::to_string(nconv + 1);
-      if ((nf / 2) % 32 == 0) { SegDesc s; s.v = cur; conv(tg, l3, {s}, hid, N2, Hl, Wl, true); }
-      else conv_pw(tg, l3, cur, hid, (int64_t)N2 * Hl * Wl, true);
-      conv_pw(tg, l4, hid, view(res[l], 0, 0, 2), (int64_t)N2 * Hl * Wl, false);
+      if ((nf / 2) % 32 == 0) {
+        SegDesc s; s.v = cur;
+        conv(tg, l3, {s}, hid, N2, Hl, Wl, true);
+        conv_pw(tg, l4, hid, view(res[l], 0, 0, 2), (int64_t)N2 * Hl * Wl, false);
+      } else {  // nf / 2 == 16: both 1x1 convs in one kernel, the 16-channel hidden layer stays in registers
+        const LayerPack& L3 = h->layers[h->layer_idx.at(l3)];
+        const LayerPack& L4 = h->layers[h->layer_idx.at(l4)];
+        OpDesc op;
+        op.kind = OP_FLOW_HEAD; op.tag = tg + ":" + l3 + "+conv_" + std::to_string(nconv + 1);
+        op.in = cur; op.out = view(res[l], 0, 0, 2); op.n = (int64_t)N2 * Hl * Wl; op.Ctot = nf;
+        op.w_off = L3.w_off; op.b_off = L3.b_off; op.w2_off = L4.w_off; op.b2_off = L4.b_off;
+        op.flops = 2.0 * op.n * (nf * 16 + 16 * 2); op.bytes = 4.0 * op.n * (nf + 2);
+        P->ops.push_back(op);
+      }
       if (l < L - 1) {
         OpDesc ad;
         ad.kind = OP_FLOW_ADD; ad.tag = tg + ":v=res+up";
@@ -553,12 +574,12 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.M = op.NB * op.H * op.W;
       return film_launch_conv(p, op.tile, s);
     }
-    case OP_CONV_C3: {
-      ConvC3Params p{};
-      p.in = cptr(arena, op.in); p.w = wts + op.w_off; p.bias = wts + op.b_off;
-      p.out = mptr(arena, op.out); p.ostride = op.out.stride;
-      p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.leaky = op.leaky;
-      return film_launch_conv_c3(p, s);
+    case OP_FLOW_HEAD: {
+      FlowHeadParams p{};
+      p.in = cptr(arena, op.in); p.istride = op.in.stride; p.Cin = op.Ctot;
+      p.w3 = wts + op.w_off; p.b3 = wts + op.b_off; p.w4 = wts + op.w2_off; p.b4 = wts + op.b2_off;
+      p.out = mptr(arena, op.out); p.M = (int)op.n;
+      return film_launch_flow_head(p, s);
     }
     case OP_CONV_PW: {
       ConvPwParams p{};
@@ -603,14 +624,18 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 }
 
 std::vector<int> tile_candidates(int Cout) {
-  if (Cout % 128 == 0) return {TILE_128x128, TILE_256x128, TILE_256x64, TILE_128x64, TILE_64x64};
-  if (Cout % 64 == 0) return {TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_128x32};
-  return {TILE_256x32, TILE_128x32};
+  std::vector<int> shapes;
+  if (Cout % 128 == 0) shapes = {TILE_128x128, TILE_256x128, TILE_256x64, TILE_128x64, TILE_64x64};
+  else if (Cout % 64 == 0) shapes = {TILE_256x64, TILE_128x64, TILE_64x64, TILE_256x32, TILE_128x32};
+  else shapes = {TILE_256x32, TILE_128x32};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh); out.push_back(sh | CONV_TILE_XCD); }
+  return out;
 }
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -636,7 +661,15 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      for (int tile : tile_candidates(op.Cout)) {
+      std::vector<int> cands = tile_candidates(op.Cout);
+      if (op.c3) {
+        cands.clear();
+        for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
+          cands.push_back(sh | CONV_TILE_C3);
+          cands.push_back(sh | CONV_TILE_C3 | CONV_TILE_XCD);
+        }
+      }
+      for (int tile : cands) {
         OpDesc trial = op;
         trial.tile = tile;
         HIPCHK(h, launch_op(trial, P->arena, h->packed_dev, h->stream));  // warm
@@ -750,7 +783,8 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
+      << ",\"b_off\":" << op.b_off << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
+      << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
     json_view(o, "in", op.in, P); o << ",";
     json_view(o, "in2", op.in2, P); o << ",";
@@ -880,6 +914,11 @@ int film_finalize(film_t* h) {
     const float* src = kw->second.data.data();
     float* dst = h->packed_host.data() + L.w_off;
     const int ct = L.ctot();
+    if (L.c3) {
+      for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < 3; ++c)
+          memcpy(dst + ((size_t)tap * 4 + c) * L.cout, src + ((size_t)tap * 3 + c) * L.cout, sizeof(float) * L.cout);
+    } else
     for (int tap = 0; tap < L.kh * L.kw; ++tap)
       for (int ci = 0; ci < ct; ++ci) {
         const int ref = L.perm[ci];

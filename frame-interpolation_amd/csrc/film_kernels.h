@@ -37,15 +37,18 @@ struct ConvParams {
   int M;
 };
 
-// First layer: Conv2D 3x3 on the 3-channel image (feature_extractor.py:119-120, cfeat_conv_0).
-struct ConvC3Params {
-  const float* in;    // [NB][H][W][3]
-  const float* w;     // [27][Cout]
-  const float* bias;
-  float* out;
-  int ostride;
-  int NB, H, W, Cout;
-  int leaky;
+// Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,
+// then 1x1 conv 16 -> 2, fused: the 16-channel intermediate stays in registers.
+struct FlowHeadParams {
+  const float* in;
+  int istride;
+  int Cin;            // multiple of 4
+  const float* w3;    // [Cin][16]
+  const float* b3;
+  const float* w4;    // [16][2]
+  const float* b4;
+  float* out;         // [M][2]
+  int M;
 };
 
 // 1x1 convolution with a tiny output width (Cout <= 16): flow heads and the RGB head.
@@ -110,12 +113,14 @@ struct PackFlowParams {
   int64_t npix;
 };
 
+// Tile id = shape index + CONV_TILE_XCD when the XCD-contiguous block mapping is used.
 enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
-                TILE_128x64 = 5, TILE_256x128 = 6, TILE_COUNT = 7 };
+                TILE_128x64 = 5, TILE_256x128 = 6 /* 8 waves, 4x2 */, TILE_SHAPES = 7, CONV_TILE_XCD = 16,
+                CONV_TILE_C3 = 32 /* first-layer mode: 3-channel image input, [48][Cout] weights */ };
 
 struct TileShape { int bm, bn; };
 static inline TileShape film_tile_shape(int tile) {
-  switch (tile) {
+  switch (tile & (CONV_TILE_XCD - 1)) {
     case TILE_128x128: return {128, 128};
     case TILE_256x64: return {256, 64};
     case TILE_256x32: return {256, 32};
@@ -127,8 +132,8 @@ static inline TileShape film_tile_shape(int tile) {
 }
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s);
-hipError_t film_launch_conv_c3(const ConvC3Params& p, hipStream_t s);
 hipError_t film_launch_conv_pw(const ConvPwParams& p, hipStream_t s);
+hipError_t film_launch_flow_head(const FlowHeadParams& p, hipStream_t s);
 hipError_t film_launch_pool(const PoolParams& p, hipStream_t s);
 hipError_t film_launch_flow_up(const FlowUpParams& p, hipStream_t s);
 hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s);

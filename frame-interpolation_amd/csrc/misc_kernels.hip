@@ -1,6 +1,6 @@
 // misc_kernels.hip -- the HBM-bound / small kernels of the FILM hot path (gfx950, wave64).
 //
-//   conv_c3      first layer, Conv2D 3x3 on the RGB image        feature_extractor.py:119-120
+//   flow_head    fused 1x1 (Cin->16, leaky) + 1x1 (16->2) flow head  pyramid_flow_estimator.py:77-83
 //   conv_pw      1x1 Conv2D with Cout <= 16 (flow / RGB heads)   pyramid_flow_estimator.py:77-83, fusion.py:100-101
 //   pool2x2      AveragePooling2D(2,2,'valid')                   util.py:39-44, feature_extractor.py:138-146
 //   flow_up      tf.image.resize(2*v) bilinear x2                pyramid_flow_estimator.py:155, util.py:113
@@ -15,50 +15,6 @@
 namespace {
 
 __device__ __forceinline__ float leaky02(float v) { return v > 0.f ? v : 0.2f * v; }
-
-// ------------------------------------------------------------------------------------------------
-// conv_c3: thread = (pixel, 4 output channels); the 27 x Cout weights live in LDS.
-// Sum order: taps row-major, then channel -- the same K order as the MFMA kernel.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv_c3_kernel(ConvC3Params p) {
-  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [27][Cout]
-  const int nw = 27 * p.Cout;
-  for (int i = threadIdx.x; i < nw; i += 256) wsm[i] = p.w[i];
-  __syncthreads();
-  const int G = p.Cout >> 2;
-  const int64_t total = (int64_t)p.NB * p.H * p.W * G;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int g = (int)(idx % G);
-  const int64_t pix = idx / G;
-  const int x = (int)(pix % p.W);
-  const int64_t t2 = pix / p.W;
-  const int y = (int)(t2 % p.H);
-  const int64_t b = t2 / p.H;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-#pragma unroll
-    for (int dx = 0; dx < 3; ++dx) {
-      const int yy = y + dy - 1, xx = x + dx - 1;
-      const bool inb = yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-      const float* src = p.in + ((b * p.H + (inb ? yy : 0)) * p.W + (inb ? xx : 0)) * 3;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const float v = inb ? src[c] : 0.f;
-        const float4 w = *reinterpret_cast<const float4*>(wsm + ((dy * 3 + dx) * 3 + c) * p.Cout + g * 4);
-        acc.x = __builtin_fmaf(v, w.x, acc.x);
-        acc.y = __builtin_fmaf(v, w.y, acc.y);
-        acc.z = __builtin_fmaf(v, w.z, acc.z);
-        acc.w = __builtin_fmaf(v, w.w, acc.w);
-      }
-    }
-  }
-  const float4 bv = *reinterpret_cast<const float4*>(p.bias + g * 4);
-  acc.x += bv.x; acc.y += bv.y; acc.z += bv.z; acc.w += bv.w;
-  if (p.leaky) { acc.x = leaky02(acc.x); acc.y = leaky02(acc.y); acc.z = leaky02(acc.z); acc.w = leaky02(acc.w); }
-  *reinterpret_cast<float4*>(p.out + pix * p.ostride + g * 4) = acc;
-}
 
 // ------------------------------------------------------------------------------------------------
 // conv_pw: thread = pixel, all COUT (<= 16) outputs in registers; weights broadcast from LDS.
@@ -91,6 +47,41 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvPwParams p) {
     if (p.leaky) v = leaky02(v);
     dst[o] = v;
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// flow_head: thread = pixel; hidden = leaky(W3^T x + b3) (16 values, registers), out = W4^T hidden + b4.
+// Same fma order as the two separate 1x1 convolutions.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void flow_head_kernel(FlowHeadParams p) {
+  extern __shared__ __attribute__((aligned(16))) float wsm[];  // [Cin][16] then [16][2]
+  const int n3 = p.Cin * 16;
+  for (int i = threadIdx.x; i < n3; i += 256) wsm[i] = p.w3[i];
+  if (threadIdx.x < 32) wsm[n3 + threadIdx.x] = p.w4[threadIdx.x];
+  __syncthreads();
+  const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= p.M) return;
+  const float* src = p.in + m * p.istride;
+  float h[16];
+#pragma unroll
+  for (int o = 0; o < 16; ++o) h[o] = 0.f;
+  for (int c = 0; c < p.Cin; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(src + c);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int o = 0; o < 16; ++o) h[o] = __builtin_fmaf(vv[k], wsm[(c + k) * 16 + o], h[o]);
+    }
+  }
+  float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    const float hv = leaky02(h[o] + p.b3[o]);
+    o0 = __builtin_fmaf(hv, wsm[n3 + o * 2], o0);
+    o1 = __builtin_fmaf(hv, wsm[n3 + o * 2 + 1], o1);
+  }
+  reinterpret_cast<float2*>(p.out)[m] = make_float2(o0 + p.b4[0], o1 + p.b4[1]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -285,12 +276,6 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
 
-hipError_t film_launch_conv_c3(const ConvC3Params& p, hipStream_t s) {
-  const int64_t total = (int64_t)p.NB * p.H * p.W * (p.Cout / 4);
-  hipLaunchKernelGGL(conv_c3_kernel, dim3(blocks_for(total)), dim3(256), 27 * p.Cout * sizeof(float), s, p);
-  return hipGetLastError();
-}
-
 hipError_t film_launch_conv_pw(const ConvPwParams& p, hipStream_t s) {
   const dim3 grid(blocks_for(p.M)), block(256);
   const size_t sh = (size_t)p.Cin * p.Cout * sizeof(float);
@@ -300,6 +285,12 @@ hipError_t film_launch_conv_pw(const ConvPwParams& p, hipStream_t s) {
     case 16: hipLaunchKernelGGL(conv_pw_kernel<16>, grid, block, sh, s, p); break;
     default: return hipErrorInvalidValue;
   }
+  return hipGetLastError();
+}
+
+hipError_t film_launch_flow_head(const FlowHeadParams& p, hipStream_t s) {
+  const size_t sh = ((size_t)p.Cin * 16 + 32) * sizeof(float);
+  hipLaunchKernelGGL(flow_head_kernel, dim3(blocks_for(p.M)), dim3(256), sh, s, p);
   return hipGetLastError();
 }
 

@@ -35,7 +35,16 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
     for op in plan['ops']:
         k = op['kind']
         nb, h, w = op['NB'], op['H'], op['W']
-        if k == 'conv_mfma':
+        if k == 'conv_mfma' and op.get('c3'):
+            # first-layer mode: 3-channel image input, weights packed [12 tap slots][4][Cout]
+            x = np.ascontiguousarray(_view(arena, op['segs'][0]['v'], nb, h, w))
+            co = op['Cout']
+            w48 = packed[op['w_off']:op['w_off'] + 48 * co].reshape(12, 4, co)
+            assert not w48[9:].any() and not w48[:, 3].any(), 'padding rows of the C3 pack must be zero'
+            wt = np.ascontiguousarray(w48[:9, :3]).reshape(3, 3, 3, co)
+            bias = packed[op['b_off']:op['b_off'] + co]
+            _view(arena, op['out'], nb, h, w)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+        elif k == 'conv_mfma':
             parts = []
             for sg in op['segs']:
                 hs, ws = (h // 2, w // 2) if sg['up'] else (h, w)
@@ -55,12 +64,16 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             _view(arena, op['out'], nb, h, w)[...] = y
-        elif k == 'conv_c3':
-            x = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
-            co = op['Cout']
-            wt = packed[op['w_off']:op['w_off'] + 27 * co].reshape(3, 3, 3, co)
-            bias = packed[op['b_off']:op['b_off'] + co]
-            _view(arena, op['out'], nb, h, w)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+        elif k == 'flow_head':
+            m = op['n']
+            x = np.ascontiguousarray(_view(arena, op['in'], 1, 1, m))
+            ci = op['Ctot']
+            w3 = packed[op['w_off']:op['w_off'] + ci * 16].reshape(1, 1, ci, 16)
+            b3 = packed[op['b_off']:op['b_off'] + 16]
+            w4 = packed[op['w2_off']:op['w2_off'] + 32].reshape(1, 1, 16, 2)
+            b4 = packed[op['b2_off']:op['b2_off'] + 2]
+            hid = fo.conv2d_same(x, w3, b3, 'leaky')
+            _view(arena, op['out'], 1, 1, m)[...] = fo.conv2d_same(hid, w4, b4, None)
         elif k == 'conv_pw':
             m = op['n']
             x = np.ascontiguousarray(_view(arena, op['in'], 1, 1, m))

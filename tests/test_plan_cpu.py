@@ -153,7 +153,7 @@ def test_plan_interpreter_matches_oracle_published_64():
     want = fo.film_forward(x0, x1, w, fo.Options())
     assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
     # algorithmic conv FLOPs of the plan == SURVEY.md 8(d): 4 246 240.6875 FLOP per padded pixel
-    flops = sum(op['flops'] for op in plan['ops'] if op['kind'].startswith('conv'))
+    flops = sum(op['flops'] for op in plan['ops'] if op['kind'].startswith('conv') or op['kind'] == 'flow_head')
     assert abs(flops / (64 * 64) - 4246240.6875) / 4246240.6875 < 1e-5
     warp_bytes = sum(op['bytes'] for op in plan['ops'] if op['kind'] == 'warp')
     assert abs(warp_bytes / (64 * 64) - 5201.58) / 5201.58 < 1e-3

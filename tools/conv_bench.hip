@@ -1,0 +1,127 @@
+// conv_bench.hip -- micro-benchmark of conv_igemm_kernel variants on the real layer shapes of a 1080p
+// 2x2-tiled forward (4 tiles of 960x576; both images / both directions batched where the engine does).
+// Development tool, not part of the product library.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/conv_bench.hip -o /tmp/conv_bench
+//   /tmp/conv_bench [reps]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../frame-interpolation_amd/csrc/conv_igemm_impl.h"
+
+#define CK(x)                                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } \
+  } while (0)
+
+__global__ void fill_kernel(float* dst, size_t n, unsigned seed, float scale) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    unsigned x = (unsigned)i * 2654435761u ^ seed ^ (unsigned)(i >> 32) * 40503u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    dst[i] = (float)(int)x * (1.0f / 2147483648.0f) * scale;
+  }
+}
+
+__global__ void checksum_kernel(const float* a, size_t n, double* out) {
+  __shared__ double sh[256];
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += fabs((double)a[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+}
+
+typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
+struct Variant { const char* name; int bm, bn, bkc; LaunchFn fn; };
+#define V(BM, BN, WM, WN, BKC, FL) {#BM "x" #BN " w" #WM "x" #WN " bk" #BKC " f" #FL, BM, BN, BKC, conv_igemm_launch<BM, BN, WM, WN, BKC, FL>}
+
+static Variant variants[] = {
+    V(128, 128, 2, 2, 16, 4),
+    V(128, 128, 2, 2, 16, 68),   // + no global loads in loop
+    V(128, 128, 2, 2, 16, 196),  // + no LDS fragment reads
+    V(128, 128, 2, 2, 16, 452),  // + no barrier  (pure MFMA loop)
+    V(128, 128, 2, 2, 16, 132),  // only: no LDS fragment reads (global + LDS stores + barrier kept)
+    V(128, 128, 2, 2, 16, 260),  // only: no barrier (racy, timing only)
+    V(256, 64, 4, 1, 16, 4), V(256, 64, 4, 1, 16, 68), V(256, 64, 4, 1, 16, 196), V(256, 64, 4, 1, 16, 452),
+    V(256, 128, 4, 2, 16, 4), V(256, 128, 4, 2, 16, 68), V(256, 128, 4, 2, 16, 452),
+    V(256, 32, 4, 1, 16, 4), V(256, 32, 4, 1, 16, 68), V(256, 32, 4, 1, 16, 452),
+};
+
+struct Shape { const char* name; int NB, H, W, C, Cout, ks; };
+static Shape shapes[] = {
+    {"fusion_1_1  M=552960 C=528->128 3x3", 4, 288, 480, 528, 128, 3},
+    {"feat_conv3  M=1.1M   C=128->128 3x3", 8, 288, 480, 128, 128, 3},
+    {"feat_conv1  M=4.4M   C=64->64 3x3", 8, 576, 960, 64, 64, 3},
+    {"flow_l0_c0  M=4.4M   C=128->32 3x3", 8, 576, 960, 128, 32, 3},
+};
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 3;
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  double* d_sum;
+  CK(hipMalloc(&d_sum, sizeof(double)));
+  for (const Shape& sh : shapes) {
+    const size_t M = (size_t)sh.NB * sh.H * sh.W;
+    const size_t n_in = M * sh.C, n_w = (size_t)sh.ks * sh.ks * sh.C * sh.Cout, n_out = M * sh.Cout;
+    float *d_in, *d_w, *d_b, *d_out;
+    CK(hipMalloc(&d_in, n_in * 4));
+    CK(hipMalloc(&d_w, n_w * 4));
+    CK(hipMalloc(&d_b, sh.Cout * 4));
+    CK(hipMalloc(&d_out, n_out * 4));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_in, n_in, 1u, 1.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_w, n_w, 2u, 0.05f);
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, st, d_b, (size_t)sh.Cout, 3u, 0.1f);
+    CK(hipStreamSynchronize(st));
+    ConvParams p{};
+    p.nseg = 1;
+    p.seg[0].ptr = d_in; p.seg[0].stride = sh.C; p.seg[0].C = sh.C;
+    p.ksize = sh.ks; p.w = d_w; p.bias = d_b; p.out = d_out; p.ostride = sh.Cout;
+    p.NB = sh.NB; p.H = sh.H; p.W = sh.W; p.Cout = sh.Cout; p.Ctot = sh.C; p.leaky = 1; p.M = (int)M;
+    const double flops = 2.0 * M * sh.Cout * sh.ks * sh.ks * sh.C;
+    printf("== %s  (%.1f GFLOP)\n", sh.name, flops * 1e-9);
+    double ref_sum = -1;
+    for (const Variant& v : variants) {
+      if (sh.Cout % v.bn || sh.C % v.bkc) continue;
+      CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
+      CK(v.fn(p, st));  // warm + correctness
+      CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
+      hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
+      double sum = 0;
+      CK(hipMemcpyAsync(&sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      if (ref_sum < 0) ref_sum = sum;
+      float best = 1e30f, tot = 0;
+      for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0, st));
+        CK(v.fn(p, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fminf(best, ms); tot += ms;
+      }
+      const double rel = fabs(sum - ref_sum) / ref_sum;
+      printf("   %-24s  min %8.3f ms  avg %8.3f ms  %7.1f TF/s  chk %s (%.1e)\n", v.name, best, tot / reps,
+             flops / best * 1e-9, rel < 1e-5 ? "ok" : "(ablation)", rel);
+      fflush(stdout);
+    }
+    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_b)); CK(hipFree(d_out));
+  }
+  return 0;
+}
