@@ -15,21 +15,25 @@
 //     bank-conflict free (MI355X_MICROARCH.md, LDS table: rows distinct mod 16 per 16-lane group).
 //   * the epilogue adds the bias, applies leaky_relu and stores 128-byte rows into the channel slice
 //     of the destination buffer (the consumer's concat input).
-// The kernel template itself lives in conv_igemm_impl.h (shared with tools/conv_bench.hip).
+// Two kernel templates:
+//   conv_buf_impl.h    the production kernel: buffer loads with hardware zero fill, K-major weights, no vector
+//                      instruction per K-step besides loads, LDS traffic and MFMAs.
+//   conv_igemm_impl.h  the first-generation kernel (64-bit pointers, select-based zero fill, [K][N] weights);
+//                      still runs the 3-channel first layer (its 4-taps-per-step mode) and is the A/B baseline
+//                      of tools/conv_bench.hip.
+#include "conv_buf_impl.h"
 #include "conv_igemm_impl.h"
 
-// Variants measured and dropped (tools/conv_bench.hip, profiles/r01_conv_bench.log): 32-channel K-steps,
-// (segment, chunk, tap) K order, s_setprio around the MFMA cluster - none faster than this form.
 template <int F>
 static hipError_t launch_shape(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
-    case TILE_128x128: return conv_igemm_launch<128, 128, 2, 2, 16, F>(p, s);
-    case TILE_256x64: return conv_igemm_launch<256, 64, 4, 1, 16, F>(p, s);
-    case TILE_256x32: return conv_igemm_launch<256, 32, 4, 1, 16, F>(p, s);
-    case TILE_64x64: return conv_igemm_launch<64, 64, 2, 2, 16, F>(p, s);
-    case TILE_128x32: return conv_igemm_launch<128, 32, 4, 1, 16, F>(p, s);
-    case TILE_128x64: return conv_igemm_launch<128, 64, 2, 2, 16, F>(p, s);
-    case TILE_256x128: return conv_igemm_launch<256, 128, 4, 2, 16, F>(p, s);
+    case TILE_128x128: return conv_buf_launch<128, 128, 2, 2, F>(p, s);
+    case TILE_256x64: return conv_buf_launch<256, 64, 4, 1, F>(p, s);
+    case TILE_256x32: return conv_buf_launch<256, 32, 4, 1, F>(p, s);
+    case TILE_64x64: return conv_buf_launch<64, 64, 2, 2, F>(p, s);
+    case TILE_128x32: return conv_buf_launch<128, 32, 4, 1, F>(p, s);
+    case TILE_128x64: return conv_buf_launch<128, 64, 2, 2, F>(p, s);
+    case TILE_256x128: return conv_buf_launch<256, 128, 4, 2, F>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -46,9 +50,11 @@ static hipError_t launch_c3(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
+
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
   if (tile & CONV_TILE_C3)
     return (tile & CONV_TILE_XCD) ? launch_c3<CONV_F_XCD_M>(p, shape, s) : launch_c3<0>(p, shape, s);
-  return (tile & CONV_TILE_XCD) ? launch_shape<CONV_F_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
+  return (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
 }

@@ -22,7 +22,10 @@ enum : int {
   CONV_F_DBG_NOGLOBAL = 64,   // no global loads / LDS stores inside the K loop
   CONV_F_DBG_NOLDSREAD = 128, // no LDS fragment reads inside the K loop (operands from registers)
   CONV_F_DBG_NOBARRIER = 256, // no barrier inside the K loop
-  CONV_F_PF1 = 512,           // single-step prefetch (the first version of the pipeline; kept for A/B runs)
+  CONV_F_PF1 = 512,
+  CONV_F_DBG_SAMEPIX = 1024,
+  CONV_F_DBG_NOLDSWRITE = 2048,  // global loads issued and waited for, but no LDS store (timing only)
+  CONV_F_DBG_NOLOAD = 4096,      // LDS stores of stale registers, no global loads (timing only)  // every A row reads pixel 0 of its image (all gathers hit L1/L2)           // single-step prefetch (the first version of the pipeline; kept for A/B runs)
 };
 
 template <int BM, int BN, int WGM, int WGN, int BKC, int FLAGS>
@@ -131,7 +134,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvParams p)
       if (s.up) { yy >>= 1; xx >>= 1; }
       int be = ab[i] + s.boff;
       if (s.bmod && be >= s.bmod) be -= s.bmod;
-      const size_t pix = ((size_t)be * Hs + (inb ? yy : 0)) * Ws + (inb ? xx : 0);
+      size_t pix = ((size_t)be * Hs + (inb ? yy : 0)) * Ws + (inb ? xx : 0);
+      if constexpr ((FLAGS & CONV_F_DBG_SAMEPIX) != 0) pix = 0;
       aptr[i] = s.ptr + pix * s.stride + acol;
       ainb[i] = inb;
     }
@@ -146,6 +150,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvParams p)
   };
   Stage sx, sy;
   auto load_global = [&](Stage& st, bool real) {  // real = false: padding step, its A rows are stored as zeros
+    if constexpr ((FLAGS & CONV_F_DBG_NOLOAD) != 0) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) { asm volatile("" : "+v"(st.a[i].x), "+v"(st.a[i].y), "+v"(st.a[i].z), "+v"(st.a[i].w)); st.inb[i] = ainb[i] && real; }
+      asm volatile("" : "+v"(st.b0.x), "+v"(st.b0.y), "+v"(st.b0.z), "+v"(st.b0.w));
+      return;
+    }
     if constexpr (C3) {
 #pragma unroll
       for (int i = 0; i < AROWS; ++i) st.a[i] = make_float4(aptr[i][0], aptr[i][1], aptr[i][2], 0.f);
@@ -163,6 +173,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_igemm_kernel(ConvParams p)
     for (int i = 0; i < AROWS; ++i) st.inb[i] = ainb[i] && real;
   };
   auto store_lds = [&](const Stage& st, int buf) {
+    if constexpr ((FLAGS & CONV_F_DBG_NOLDSWRITE) != 0) {
+#pragma unroll
+      for (int i = 0; i < AROWS; ++i) asm volatile("" ::"v"(st.a[i].x), "v"(st.a[i].y), "v"(st.a[i].z), "v"(st.a[i].w));
+      asm volatile("" ::"v"(st.b0.x), "v"(st.b0.w));
+      if constexpr (BLD > 1) asm volatile("" ::"v"(st.b1.x), "v"(st.b1.w));
+      if constexpr (BLD > 2) asm volatile("" ::"v"(st.b2.x), "v"(st.b2.w));
+      if constexpr (BLD > 3) asm volatile("" ::"v"(st.b3.x), "v"(st.b3.w));
+      return;
+    }
     float* As = smem + buf * (A_SZ + B_SZ);
     float* Bs = As + A_SZ;
 #pragma unroll

@@ -79,6 +79,9 @@ struct LayerPack {
   int kh, kw, cin, cout;     // reference shape
   std::vector<int> perm;     // internal input channel -> reference input channel, -1 = zero row
   bool c3 = false;           // first layer: packed as [12 tap slots][4][Cout] (row = tap*4 + channel, rest zero)
+  // layers run by the MFMA conv kernel (Cout % 32 == 0) are packed K-contiguous per output channel:
+  // [Cout][kh*kw*ctot] with k = tap*ctot + channel; the 1x1 heads keep [ctot][Cout]
+  bool kmajor() const { return !c3 && cout % 32 == 0; }
   int64_t w_off = 0, b_off = 0;
   int ctot() const { return (int)perm.size(); }
   int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
@@ -333,7 +336,7 @@ struct Planner {
     int ctot = 0;
     for (int i = 0; i < op.nseg; ++i) { op.seg[i] = segs[i]; ctot += segs[i].v.C; }
     op.ksize = L.kh; op.leaky = leaky; op.Cout = L.cout; op.Ctot = ctot;
-    if (ctot != L.ctot() || out.C != L.cout || op.nseg > FILM_MAX_SEG) {
+    if (ctot != L.ctot() || out.C != L.cout || op.nseg > FILM_MAX_SEG || !L.kmajor()) {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
@@ -918,6 +921,16 @@ int film_finalize(film_t* h) {
       for (int tap = 0; tap < 9; ++tap)
         for (int c = 0; c < 3; ++c)
           memcpy(dst + ((size_t)tap * 4 + c) * L.cout, src + ((size_t)tap * 3 + c) * L.cout, sizeof(float) * L.cout);
+    } else if (L.kmajor()) {
+      const size_t ktot = (size_t)L.kh * L.kw * ct;
+      for (int tap = 0; tap < L.kh * L.kw; ++tap)
+        for (int ci = 0; ci < ct; ++ci) {
+          const int ref = L.perm[ci];
+          if (ref < 0) continue;  // zero column (padding channel)
+          const float* row = src + ((size_t)tap * L.cin + ref) * L.cout;
+          float* col = dst + (size_t)tap * ct + ci;
+          for (int co = 0; co < L.cout; ++co) col[co * ktot] = row[co];
+        }
     } else
     for (int tap = 0; tap < L.kh * L.kw; ++tap)
       for (int ci = 0; ci < ct; ++ci) {
@@ -990,11 +1003,46 @@ int film_profile_json(film_t* h, char* buf, int64_t cap, int64_t* needed) {
   return copy_out_string(h, h->profile_json, buf, cap, needed);
 }
 
+namespace {
+// The conv kernel addresses its inputs with 32-bit byte offsets (buffer loads): every activation buffer of a plan
+// must stay below 4 GiB.  Largest buffer of a B = 1 plan, in bytes (buffers scale linearly with the batch).
+int64_t unit_buffer_bytes(film_t* h, int H, int W, int* rc) {
+  Plan* P1 = nullptr;
+  *rc = get_plan(h, 1, H, W, false, &P1);
+  if (*rc) return 0;
+  int64_t mx = 0;
+  for (const Buffer& b : P1->bufs) mx = std::max(mx, b.floats * (int64_t)sizeof(float));
+  return mx;
+}
+constexpr int64_t kMaxBufferBytes = 0xFFF00000ll;
+
+int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream);
+}  // namespace
+
 int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream) {
   if (!h || !x0 || !x1 || !out) return fail(h, FILM_ERR_INVALID, "NULL argument");
   if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle: film_forward needs a HIP device (no CPU fallback)");
   if (!h->finalized) return fail(h, FILM_ERR_STATE, "film_finalize has not been called");
   if (mem_kind != FILM_MEM_HOST && mem_kind != FILM_MEM_DEVICE) return fail(h, FILM_ERR_INVALID, "bad mem_kind");
+  if (B < 1) return fail(h, FILM_ERR_INVALID, "B, H, W must be positive");
+  int rc = 0;
+  const int64_t unit = unit_buffer_bytes(h, H, W, &rc);
+  if (rc) return rc;
+  if (unit > kMaxBufferBytes)
+    return fail(h, FILM_ERR_INVALID, "a %d x %d frame needs a %.1f GB activation buffer; the conv kernel addresses 4 GiB per "
+                "buffer - tile the frame (Interpolator block_shape)", H, W, unit * 1e-9);
+  const int bmax = (int)std::max<int64_t>(1, kMaxBufferBytes / unit);
+  const size_t frame = (size_t)H * W * 3;
+  for (int b0 = 0; b0 < B; b0 += bmax) {  // independent frame pairs: the batch splits with no change in results
+    const int nb = std::min(bmax, B - b0);
+    rc = forward_chunk(h, x0 + b0 * frame, x1 + b0 * frame, nb, H, W, out + b0 * frame, mem_kind, stream);
+    if (rc) return rc;
+  }
+  return FILM_OK;
+}
+
+namespace {
+int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream) {
   HIPCHK(h, hipSetDevice(h->device));
   Plan* P = nullptr;
   int rc = get_plan(h, B, H, W, true, &P);
@@ -1062,6 +1110,8 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
   h->last_plan = P;
   return FILM_OK;
 }
+
+}  // namespace
 
 int film_get_tap(film_t* h, const char* name, float* dst, int64_t cap, int64_t dims[4]) {
   if (!h || !name) return FILM_ERR_INVALID;

@@ -23,11 +23,13 @@ struct ConvSeg {
 
 // Conv2D(padding='same', stride 1) [+ bias] [+ leaky_relu(0.2)] as implicit GEMM:
 //   M = NB*H*W output pixels, N = Cout, K = ksize^2 * Ctot, K ordered (tap, segment, channel).
+// Every segment is addressed with 32-bit byte offsets from seg.ptr: the buffer behind it must be < 4 GiB.
 struct ConvParams {
   ConvSeg seg[FILM_MAX_SEG];
   int nseg;
   int ksize;          // 1, 2, 3; TF 'same': pad_before = (ksize-1)/2, rest after
-  const float* w;     // packed [ksize*ksize][Ctot][Cout]
+  const float* w;     // conv_buf_kernel: packed [Cout][ksize*ksize*Ctot] (K contiguous per output channel);
+                      // conv_igemm_kernel: [ksize*ksize*Ctot][Cout] ([48][Cout] in first-layer mode)
   const float* bias;  // [Cout]
   float* out;         // [NB][H][W][ostride], first output channel
   int ostride;

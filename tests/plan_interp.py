@@ -60,7 +60,9 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             x = np.ascontiguousarray(np.concatenate(parts, axis=-1))
             ks, ct, co = op['ksize'], op['Ctot'], op['Cout']
             assert x.shape[-1] == ct
-            wt = packed[op['w_off']:op['w_off'] + ks * ks * ct * co].reshape(ks, ks, ct, co)
+            # MFMA-conv layers are packed K-major: [Cout][tap][Ctot]
+            wt = packed[op['w_off']:op['w_off'] + ks * ks * ct * co].reshape(co, ks, ks, ct)
+            wt = np.ascontiguousarray(wt.transpose(1, 2, 3, 0))
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             _view(arena, op['out'], nb, h, w)[...] = y

@@ -96,7 +96,9 @@ def test_packing_permutes_fusion_inputs(tiny_weights):
     L = {l['name']: l for l in plan['layers']}['fusion/convs_0_1']
     C = W.feature_channels(TINY)[0]
     ref = tiny_weights['fusion/convs_0_1/kernel']
-    packed = blob[L['w_off']:L['w_off'] + 9 * L['ctot'] * L['cout']].reshape(3, 3, L['ctot'], L['cout'])
+    # MFMA-conv layers are packed K-major ([Cout][tap][ctot]); back to HWIO for the comparison
+    packed = blob[L['w_off']:L['w_off'] + 9 * L['ctot'] * L['cout']].reshape(L['cout'], 3, 3, L['ctot'])
+    packed = packed.transpose(1, 2, 3, 0)
     assert L['ctot'] == 2 * C + 16 + L['cout']
     assert np.array_equal(packed[:, :, :C], ref[:, :, 3:3 + C])                       # feat0
     assert np.array_equal(packed[:, :, C:2 * C], ref[:, :, 6 + C:6 + 2 * C])           # feat1

@@ -9,10 +9,13 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
 #include "../frame-interpolation_amd/csrc/conv_igemm_impl.h"
+#include "experiments/conv_dma_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
 
 #define CK(x)                                                                              \
   do {                                                                                     \
@@ -44,20 +47,32 @@ __global__ void checksum_kernel(const float* a, size_t n, double* out) {
 }
 
 typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
-struct Variant { const char* name; int bm, bn, bkc; LaunchFn fn; };
-#define V(BM, BN, WM, WN, BKC, FL) {#BM "x" #BN " w" #WM "x" #WN " bk" #BKC " f" #FL, BM, BN, BKC, conv_igemm_launch<BM, BN, WM, WN, BKC, FL>}
+struct Variant { const char* name; int bm, bn, bkc; bool dma; LaunchFn fn; };
+#define V(BM, BN, WM, WN, BKC, FL) {#BM "x" #BN " w" #WM "x" #WN " bk" #BKC " f" #FL, BM, BN, BKC, false, conv_igemm_launch<BM, BN, WM, WN, BKC, FL>}
+#define D(BM, BN, WM, WN, FL) {"dma " #BM "x" #BN " w" #WM "x" #WN " f" #FL, BM, BN, 16, true, conv_dma_launch<BM, BN, WM, WN, FL>}
 
+#define B(BM, BN, WM, WN, FL) {"buf " #BM "x" #BN " w" #WM "x" #WN " f" #FL, BM, BN, 16, true, conv_buf_launch<BM, BN, WM, WN, FL>}
 static Variant variants[] = {
-    V(128, 128, 2, 2, 16, 4),
-    V(128, 128, 2, 2, 16, 68),   // + no global loads in loop
-    V(128, 128, 2, 2, 16, 196),  // + no LDS fragment reads
-    V(128, 128, 2, 2, 16, 452),  // + no barrier  (pure MFMA loop)
-    V(128, 128, 2, 2, 16, 132),  // only: no LDS fragment reads (global + LDS stores + barrier kept)
-    V(128, 128, 2, 2, 16, 260),  // only: no barrier (racy, timing only)
-    V(256, 64, 4, 1, 16, 4), V(256, 64, 4, 1, 16, 68), V(256, 64, 4, 1, 16, 196), V(256, 64, 4, 1, 16, 452),
-    V(256, 128, 4, 2, 16, 4), V(256, 128, 4, 2, 16, 68), V(256, 128, 4, 2, 16, 452),
-    V(256, 32, 4, 1, 16, 4), V(256, 32, 4, 1, 16, 68), V(256, 32, 4, 1, 16, 452),
+    V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4), B(256, 64, 4, 1, 4), B(128, 64, 2, 2, 4), B(64, 64, 2, 2, 4),
+    B(256, 128, 4, 2, 4), B(256, 32, 4, 1, 4), B(128, 32, 4, 1, 4),
+    D(128, 128, 2, 2, 4), D(128, 128, 2, 2, 0),
+    D(128, 128, 2, 2, 68), D(128, 128, 2, 2, 132), D(128, 128, 2, 2, 260), D(128, 128, 2, 2, 388), D(128, 128, 2, 2, 324),
+    D(64, 64, 1, 1, 4), D(64, 64, 1, 1, 68), D(64, 64, 1, 1, 132),
+    V(128, 128, 2, 2, 16, 2052), V(128, 128, 2, 2, 16, 4100), V(128, 128, 2, 2, 16, 1028), D(128, 128, 2, 2, 1028),  // ablation: all A gathers from one pixel
+    V(128, 128, 2, 2, 16, 68),   // ablation: no global loads / LDS stores in the loop
+    V(128, 128, 2, 2, 16, 452),  // ablation: pure MFMA loop
+    V(256, 64, 4, 1, 16, 4),  D(256, 64, 4, 1, 4),
+    D(128, 64, 2, 2, 4), D(64, 64, 2, 2, 4), D(256, 128, 4, 2, 4), D(128, 256, 2, 4, 4),
+    V(256, 32, 4, 1, 16, 4),  D(256, 32, 4, 1, 4), D(128, 32, 4, 1, 4),
 };
+
+// [K][N] -> [N][K]
+__global__ void transpose_kernel(const float* src, float* dst, int K, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)K * N) return;
+  const int k = (int)(i / N), n = (int)(i % N);
+  dst[(size_t)n * K + k] = src[i];
+}
 
 struct Shape { const char* name; int NB, H, W, C, Cout, ks; };
 static Shape shapes[] = {
@@ -69,6 +84,8 @@ static Shape shapes[] = {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 3;
+  const int only_shape = argc > 2 ? atoi(argv[2]) : -1;      // -1: all shapes
+  const char* only_variant = argc > 3 ? argv[3] : nullptr;   // substring filter on the variant name
   hipStream_t st;
   CK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
@@ -76,17 +93,23 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e1));
   double* d_sum;
   CK(hipMalloc(&d_sum, sizeof(double)));
+  int shape_idx = -1;
   for (const Shape& sh : shapes) {
+    if (++shape_idx != only_shape && only_shape >= 0) continue;
     const size_t M = (size_t)sh.NB * sh.H * sh.W;
     const size_t n_in = M * sh.C, n_w = (size_t)sh.ks * sh.ks * sh.C * sh.Cout, n_out = M * sh.Cout;
-    float *d_in, *d_w, *d_b, *d_out;
+    float *d_in, *d_w, *d_wt, *d_b, *d_out, *d_zero;
     CK(hipMalloc(&d_in, n_in * 4));
     CK(hipMalloc(&d_w, n_w * 4));
+    CK(hipMalloc(&d_wt, n_w * 4));
+    CK(hipMalloc(&d_zero, 256));
+    CK(hipMemset(d_zero, 0, 256));
     CK(hipMalloc(&d_b, sh.Cout * 4));
     CK(hipMalloc(&d_out, n_out * 4));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_in, n_in, 1u, 1.0f);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_w, n_w, 2u, 0.05f);
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, st, d_b, (size_t)sh.Cout, 3u, 0.1f);
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wt, sh.ks * sh.ks * sh.C, sh.Cout);
     CK(hipStreamSynchronize(st));
     ConvParams p{};
     p.nseg = 1;
@@ -98,7 +121,9 @@ int main(int argc, char** argv) {
     double ref_sum = -1;
     for (const Variant& v : variants) {
       if (sh.Cout % v.bn || sh.C % v.bkc) continue;
+      if (only_variant && !strstr(v.name, only_variant)) continue;
       CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
+      p.w = v.dma ? d_wt : d_w;
       CK(v.fn(p, st));  // warm + correctness
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
       hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
@@ -121,7 +146,7 @@ int main(int argc, char** argv) {
              flops / best * 1e-9, rel < 1e-5 ? "ok" : "(ablation)", rel);
       fflush(stdout);
     }
-    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_b)); CK(hipFree(d_out));
+    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   return 0;
 }
