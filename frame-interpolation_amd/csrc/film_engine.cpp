@@ -112,6 +112,8 @@ struct Plan {
 }  // namespace
 
 struct film_handle {
+  void* stage = nullptr;       // device staging of whole frames for film_interpolate(FILM_MEM_HOST)
+  size_t stage_bytes = 0;
   int device = -1;
   bool plan_only = true;
   film_config cfg{};
@@ -128,6 +130,7 @@ struct film_handle {
   Plan* last_plan = nullptr;
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
+  int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
 };
@@ -869,6 +872,7 @@ void film_destroy(film_t* h) {
   }
   for (auto& p : h->plans) free_plan(p.get());
   if (h->packed_dev) (void)hipFree(h->packed_dev);
+  if (h->stage) (void)hipFree(h->stage);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -985,6 +989,7 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   if (!strcmp(key, "graph")) h->opt_graph = value != 0;
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
+  else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
   else return fail(h, FILM_ERR_NOTFOUND, "unknown option '%s'", key);
   return FILM_OK;
 }
@@ -1017,6 +1022,8 @@ int64_t unit_buffer_bytes(film_t* h, int H, int W, int* rc) {
 constexpr int64_t kMaxBufferBytes = 0xFFF00000ll;
 
 int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream);
+int run_plan(film_t* h, Plan* P, hipStream_t s);
+hipStream_t pick_stream(film_t* h, int mem_kind, void* stream);
 }  // namespace
 
 int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream) {
@@ -1031,7 +1038,8 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
   if (unit > kMaxBufferBytes)
     return fail(h, FILM_ERR_INVALID, "a %d x %d frame needs a %.1f GB activation buffer; the conv kernel addresses 4 GiB per "
                 "buffer - tile the frame (Interpolator block_shape)", H, W, unit * 1e-9);
-  const int bmax = (int)std::max<int64_t>(1, kMaxBufferBytes / unit);
+  int bmax = (int)std::max<int64_t>(1, kMaxBufferBytes / unit);
+  if (h->opt_max_batch) bmax = std::min(bmax, h->opt_max_batch);
   const size_t frame = (size_t)H * W * 3;
   for (int b0 = 0; b0 < B; b0 += bmax) {  // independent frame pairs: the batch splits with no change in results
     const int nb = std::min(bmax, B - b0);
@@ -1041,24 +1049,78 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
   return FILM_OK;
 }
 
-namespace {
-int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream) {
+int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, int W, int align, int block_h,
+                     int block_w, float* out, int mem_kind, void* stream) {
+  if (!h || !x0 || !x1 || !out) return fail(h, FILM_ERR_INVALID, "NULL argument");
+  if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle: film_interpolate needs a HIP device (no CPU fallback)");
+  if (!h->finalized) return fail(h, FILM_ERR_STATE, "film_finalize has not been called");
+  if (mem_kind != FILM_MEM_HOST && mem_kind != FILM_MEM_DEVICE) return fail(h, FILM_ERR_INVALID, "bad mem_kind");
+  if (B < 1 || H < 1 || W < 1) return fail(h, FILM_ERR_INVALID, "B, H, W must be positive");
+  const int bh = block_h > 0 ? block_h : 1, bw = block_w > 0 ? block_w : 1;
+  if (bh * bw > 1 && B != 1) return fail(h, FILM_ERR_INVALID, "the tiled path takes one frame pair (eval/interpolator.py:192-206)");
+  // the reference's asserts (eval/interpolator.py:84-89), same messages
+  if (H % bh) return fail(h, FILM_ERR_INVALID, "block_height=%d should evenly divide height=%d.", bh, H);
+  if (W % bw) return fail(h, FILM_ERR_INVALID, "block_width=%d should evenly divide width=%d.", bw, W);
+  TileMapParams tp{};
+  tp.B = B; tp.H = H; tp.W = W; tp.bh = bh; tp.bw = bw; tp.ph = H / bh; tp.pw = W / bw;
+  const int hp = (align > 0 && tp.ph % align) ? align - tp.ph % align : 0;   // _pad_to_align, eval/interpolator.py:45-52
+  const int wp = (align > 0 && tp.pw % align) ? align - tp.pw % align : 0;
+  tp.TH = tp.ph + hp; tp.TW = tp.pw + wp; tp.oy = hp / 2; tp.ox = wp / 2;
   HIPCHK(h, hipSetDevice(h->device));
-  Plan* P = nullptr;
-  int rc = get_plan(h, B, H, W, true, &P);
+  int rc = 0;
+  const int64_t unit = unit_buffer_bytes(h, tp.TH, tp.TW, &rc);
   if (rc) return rc;
-  // stream == NULL: host buffers -> the handle's own (non-blocking) stream, synchronised before returning;
-  // device buffers -> the NULL (legacy default) stream, i.e. ordered with the caller's default-stream work
-  // (torch's default stream IS the NULL stream, and its handle is 0).
-  hipStream_t s = stream ? (hipStream_t)stream : (mem_kind == FILM_MEM_DEVICE ? (hipStream_t) nullptr : h->stream);
-  const size_t in_bytes = (size_t)B * H * W * 3 * sizeof(float);
-  const hipMemcpyKind kin = mem_kind == FILM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
-  const hipMemcpyKind kout = mem_kind == FILM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-  const Buffer& img0 = P->bufs[P->find("img0")];
-  const Buffer& ob = P->bufs[P->find("out")];
-  HIPCHK(h, hipMemcpyAsync(P->arena + img0.off, x0, in_bytes, kin, s));
-  HIPCHK(h, hipMemcpyAsync(P->arena + img0.off + (int64_t)B * H * W * 3, x1, in_bytes, kin, s));
+  if (unit > kMaxBufferBytes)
+    return fail(h, FILM_ERR_INVALID, "a %d x %d tile needs a %.1f GB activation buffer; the conv kernel addresses 4 GiB per "
+                "buffer - use a finer block_shape", tp.TH, tp.TW, unit * 1e-9);
+  const int ntiles = B * bh * bw;
+  int tmax = (int)std::max<int64_t>(1, kMaxBufferBytes / unit);
+  if (h->opt_max_batch) tmax = std::min(tmax, h->opt_max_batch);
+  hipStream_t s = pick_stream(h, mem_kind, stream);
+  const size_t frame_bytes = (size_t)B * H * W * 3 * sizeof(float);
+  const float *d0 = x0, *d1 = x1;
+  float* dout = out;
+  if (mem_kind == FILM_MEM_HOST) {  // stage whole frames in HBM: [x0 | x1 | out]
+    if (h->stage_bytes < 3 * frame_bytes) {
+      if (h->stage) { HIPCHK(h, hipStreamSynchronize(s)); HIPCHK(h, hipFree(h->stage)); h->stage = nullptr; h->stage_bytes = 0; }
+      hipError_t e = hipMalloc(&h->stage, 3 * frame_bytes);
+      if (e != hipSuccess) return fail(h, FILM_ERR_NOMEM, "frame staging hipMalloc of %.1f MB failed", 3 * frame_bytes * 1e-6);
+      h->stage_bytes = 3 * frame_bytes;
+    }
+    float* st = (float*)h->stage;
+    const size_t nf = frame_bytes / sizeof(float);
+    HIPCHK(h, hipMemcpyAsync(st, x0, frame_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(st + nf, x1, frame_bytes, hipMemcpyHostToDevice, s));
+    d0 = st; d1 = st + nf; dout = st + 2 * nf;
+  }
+  for (int t0 = 0; t0 < ntiles; t0 += tmax) {
+    const int nt = std::min(tmax, ntiles - t0);
+    Plan* P = nullptr;
+    rc = get_plan(h, nt, tp.TH, tp.TW, true, &P);
+    if (rc) return rc;
+    const Buffer& img0 = P->bufs[P->find("img0")];
+    const Buffer& ob = P->bufs[P->find("out")];
+    tp.tile0 = t0; tp.ntiles = nt;
+    tp.src = d0; tp.dst = P->arena + img0.off;
+    HIPCHK(h, film_launch_frame_to_tiles(tp, s));
+    tp.src = d1; tp.dst = P->arena + img0.off + (int64_t)nt * tp.TH * tp.TW * 3;
+    HIPCHK(h, film_launch_frame_to_tiles(tp, s));
+    rc = run_plan(h, P, s);
+    if (rc) return rc;
+    tp.src = P->arena + ob.off; tp.dst = dout;
+    HIPCHK(h, film_launch_tiles_to_frame(tp, s));
+  }
+  if (mem_kind == FILM_MEM_HOST) {
+    HIPCHK(h, hipMemcpyAsync(out, dout, frame_bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+  }
+  return FILM_OK;
+}
 
+namespace {
+// Executes the plan on stream s (inputs already in the plan's img0 buffer, result left in its out buffer).
+int run_plan(film_t* h, Plan* P, hipStream_t s) {
+  const int B = P->B, H = P->H, W = P->W;
   if (h->opt_profile) {
     const size_t n = P->ops.size();
     while (P->ev.size() < n + 1) { hipEvent_t e; HIPCHK(h, hipEventCreate(&e)); P->ev.push_back(e); }
@@ -1105,12 +1167,36 @@ int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int
   } else {
     for (const OpDesc& op : P->ops) HIPCHK(h, launch_op(op, P->arena, h->packed_dev, s));
   }
-  HIPCHK(h, hipMemcpyAsync(out, P->arena + ob.off, in_bytes, kout, s));
-  if (mem_kind == FILM_MEM_HOST) HIPCHK(h, hipStreamSynchronize(s));
   h->last_plan = P;
   return FILM_OK;
 }
 
+hipStream_t pick_stream(film_t* h, int mem_kind, void* stream) {
+  // stream == NULL: host buffers -> the handle's own (non-blocking) stream, synchronised before returning;
+  // device buffers -> the NULL (legacy default) stream, i.e. ordered with the caller's default-stream work
+  // (torch's default stream IS the NULL stream, and its handle is 0).
+  return stream ? (hipStream_t)stream : (mem_kind == FILM_MEM_DEVICE ? (hipStream_t) nullptr : h->stream);
+}
+
+int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream) {
+  HIPCHK(h, hipSetDevice(h->device));
+  Plan* P = nullptr;
+  int rc = get_plan(h, B, H, W, true, &P);
+  if (rc) return rc;
+  hipStream_t s = pick_stream(h, mem_kind, stream);
+  const size_t in_bytes = (size_t)B * H * W * 3 * sizeof(float);
+  const hipMemcpyKind kin = mem_kind == FILM_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice;
+  const hipMemcpyKind kout = mem_kind == FILM_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+  const Buffer& img0 = P->bufs[P->find("img0")];
+  const Buffer& ob = P->bufs[P->find("out")];
+  HIPCHK(h, hipMemcpyAsync(P->arena + img0.off, x0, in_bytes, kin, s));
+  HIPCHK(h, hipMemcpyAsync(P->arena + img0.off + (int64_t)B * H * W * 3, x1, in_bytes, kin, s));
+  rc = run_plan(h, P, s);
+  if (rc) return rc;
+  HIPCHK(h, hipMemcpyAsync(out, P->arena + ob.off, in_bytes, kout, s));
+  if (mem_kind == FILM_MEM_HOST) HIPCHK(h, hipStreamSynchronize(s));
+  return FILM_OK;
+}
 }  // namespace
 
 int film_get_tap(film_t* h, const char* name, float* dst, int64_t cap, int64_t dims[4]) {

@@ -115,6 +115,20 @@ struct PackFlowParams {
   int64_t npix;
 };
 
+// Interpolator.__call__ data movement (eval/interpolator.py:30-63 _pad_to_align, :66-126 image_to_patches /
+// patches_to_image, :192-206): frame [B][H][W][3] <-> tiles [B*bh*bw][TH][TW][3], tile n = (b, ty, tx) row-major,
+// each patch (H/bh x W/bw) zero-padded to (TH, TW) with the patch at offset (oy, ox) = (pad_h//2, pad_w//2).
+struct TileMapParams {
+  const float* src;
+  float* dst;
+  int B, H, W;       // frame
+  int bh, bw;        // blocks per frame
+  int ph, pw;        // patch = H/bh x W/bw
+  int TH, TW;        // padded tile
+  int oy, ox;        // patch offset inside the tile
+  int tile0, ntiles; // tiles [tile0, tile0 + ntiles) of the frame batch are in the tile buffer
+};
+
 // Tile id = shape index + CONV_TILE_XCD when the XCD-contiguous block mapping is used.
 enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
                 TILE_128x64 = 5, TILE_256x128 = 6 /* 8 waves, 4x2 */, TILE_SHAPES = 7, CONV_TILE_XCD = 16,
@@ -141,5 +155,7 @@ hipError_t film_launch_flow_up(const FlowUpParams& p, hipStream_t s);
 hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s);
 hipError_t film_launch_warp(const WarpParams& p, hipStream_t s);
 hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s);
+hipError_t film_launch_frame_to_tiles(const TileMapParams& p, hipStream_t s);   // pad + image_to_patches
+hipError_t film_launch_tiles_to_frame(const TileMapParams& p, hipStream_t s);   // crop + patches_to_image
 // fills n floats with a deterministic pseudo-random pattern in [-1, 1) (autotune inputs only)
 hipError_t film_launch_fill_random(float* dst, int64_t n, uint32_t seed, hipStream_t s);

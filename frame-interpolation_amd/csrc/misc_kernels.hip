@@ -330,6 +330,54 @@ hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ---- Interpolator.__call__ data movement ----------------------------------------------------------------
+// thread = one float of the tile buffer (frame_to_tiles) / of the frame (tiles_to_frame); both sides are
+// contiguous in x*3+c, so consecutive threads read and write consecutive floats of a row.
+__global__ __launch_bounds__(256) void frame_to_tiles_kernel(TileMapParams p) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int row = p.TW * 3;
+  const int64_t total = (int64_t)p.ntiles * p.TH * row;
+  if (i >= total) return;
+  const int xc = (int)(i % row);
+  const int64_t r = i / row;
+  const int y = (int)(r % p.TH);
+  const int n = (int)(r / p.TH) + p.tile0;
+  const int b = n / (p.bh * p.bw), t = n % (p.bh * p.bw);
+  const int ty = t / p.bw, tx = t % p.bw;
+  const int sy = y - p.oy, sxc = xc - p.ox * 3;
+  float v = 0.f;  // tf.image.pad_to_bounding_box pads with zeros
+  if (sy >= 0 && sy < p.ph && sxc >= 0 && sxc < p.pw * 3)
+    v = p.src[(((int64_t)b * p.H + ty * p.ph + sy) * p.W + tx * p.pw) * 3 + sxc];
+  p.dst[i] = v;
+}
+
+__global__ __launch_bounds__(256) void tiles_to_frame_kernel(TileMapParams p) {
+  // thread = one float of the patches [tile0, tile0 + ntiles) as they lie in the frame
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int row = p.pw * 3;
+  const int64_t total = (int64_t)p.ntiles * p.ph * row;
+  if (i >= total) return;
+  const int xc = (int)(i % row);
+  const int64_t r = i / row;
+  const int y = (int)(r % p.ph);
+  const int ln = (int)(r / p.ph);
+  const int n = ln + p.tile0;
+  const int b = n / (p.bh * p.bw), t = n % (p.bh * p.bw);
+  const int ty = t / p.bw, tx = t % p.bw;
+  const float v = p.src[(((int64_t)ln * p.TH + p.oy + y) * p.TW + p.ox) * 3 + xc];
+  p.dst[(((int64_t)b * p.H + ty * p.ph + y) * p.W + tx * p.pw) * 3 + xc] = v;
+}
+
+hipError_t film_launch_frame_to_tiles(const TileMapParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(frame_to_tiles_kernel, dim3(blocks_for((int64_t)p.ntiles * p.TH * p.TW * 3)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t film_launch_tiles_to_frame(const TileMapParams& p, hipStream_t s) {
+  hipLaunchKernelGGL(tiles_to_frame_kernel, dim3(blocks_for((int64_t)p.ntiles * p.ph * p.pw * 3)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
 hipError_t film_launch_fill_random(float* dst, int64_t n, uint32_t seed, hipStream_t s) {
   hipLaunchKernelGGL(fill_random_kernel, dim3(4096), dim3(256), 0, s, dst, n, seed);
   return hipGetLastError();

@@ -11,10 +11,11 @@ Usage (unchanged from the reference, eval/interpolator.py:15-24):
 
 What changed underneath: ``tf.saved_model.load`` + ``self._model(...)`` (reference
 eval/interpolator.py:148,170-172) are replaced by ``film_create/film_set_weight/film_finalize`` +
-``film_forward`` of libfilm_hip.so (include/film_hip.h).  Padding, cropping and patch
-(un)folding are host-side numpy, with the reference's exact layout rules; the patches of a tiled
-frame are independent (reference loops over them with B=1, :199-202) and are sent to the GPU as
-ONE batch.  There is no TensorFlow and no CPU fallback: without the built library and a gfx950
+``film_interpolate`` of libfilm_hip.so (include/film_hip.h).  Padding, cropping and patch
+(un)folding follow the reference's exact layout rules and run as HIP kernels inside that call; the
+numpy helpers below (_pad_to_align, image_to_patches, patches_to_image) stay importable, as in the
+reference, and are what the tests hold the device path to.  The patches of a tiled frame are
+independent (reference loops over them with B=1, :199-202) and go through the GPU as ONE batch.  There is no TensorFlow and no CPU fallback: without the built library and a gfx950
 device, construction raises.
 """
 from typing import List, Optional
@@ -126,18 +127,13 @@ class Interpolator:
                   dt: np.ndarray) -> np.ndarray:
     """Mid-frame for every pair of the batch (reference: Interpolator.interpolate, :152-176).
 
-    x0, x1 are float32 [B,H,W,3]; dt is [B] and unused by film_net.  Pads to `align`, runs one
-    film_forward on the GPU, crops back.  Output is float32 [B,H,W,3], NOT clipped to [0,1].
+    x0, x1 are float32 [B,H,W,3]; dt is [B] and unused by film_net.  Pads to `align`, runs the
+    model, crops back - one film_interpolate call.  Output is float32 [B,H,W,3], NOT clipped to [0,1].
     """
     if self._align is not None:
-      x0, bbox_to_crop = _pad_to_align(x0, self._align)
-      x1, _ = _pad_to_align(x1, self._align)
-
-    image = self._engine.forward(x0, x1)
-
-    if self._align is not None:
-      image = np.ascontiguousarray(_crop_to_bounding_box(image, **bbox_to_crop))
-    return image
+      assert np.ndim(x0) == 4
+      assert self._align > 0, 'align must be a positive number.'
+    return self._engine.interpolate_frames(x0, x1, align=self._align)
 
   def __call__(self, x0: np.ndarray, x1: np.ndarray,
                dt: np.ndarray) -> np.ndarray:
@@ -145,12 +141,16 @@ class Interpolator:
     non-overlapping patches that are padded, interpolated and cropped independently and then
     stitched back (reference: Interpolator.__call__, :178-209)."""
     if self._block_shape is not None and np.prod(self._block_shape) > 1:
-      x0_patches = image_to_patches(x0, self._block_shape)
-      x1_patches = image_to_patches(x1, self._block_shape)
-
+      block_height, block_width = self._block_shape
+      height, width = x0.shape[-3:-1]
+      # the reference's checks (image_to_patches, eval/interpolator.py:84-89)
+      assert height == (height // block_height) * block_height, (
+          'block_height=%d should evenly divide height=%d.' % (block_height, height))
+      assert width == (width // block_width) * block_width, (
+          'block_width=%d should evenly divide width=%d.' % (block_width, width))
       # The reference runs the patches one by one with B=1; they are independent, so all of
       # them go through the engine as one batch (identical per-patch arithmetic).
-      output_patches = self.interpolate(x0_patches, x1_patches, dt)
-
-      return patches_to_image(output_patches, self._block_shape)
+      x0 = np.reshape(x0, (-1, height, width, x0.shape[-1]))[:1]
+      x1 = np.reshape(x1, (-1, height, width, x1.shape[-1]))[:1]
+      return self._engine.interpolate_frames(x0, x1, align=self._align, block_shape=self._block_shape)
     return self.interpolate(x0, x1, dt)

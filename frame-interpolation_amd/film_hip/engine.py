@@ -43,6 +43,7 @@ class _Config(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     'film_default_config', 'film_create', 'film_destroy', 'film_last_error', 'film_set_weight',
     'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_forward',
+    'film_interpolate',
     'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_version')
 
 _lib = None
@@ -80,6 +81,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_export_packed.argtypes = [vp, fp, ctypes.c_int64, ctypes.c_int]
     lib.film_import_packed.argtypes = [vp, fp, ctypes.c_int64, ctypes.c_int]
     lib.film_forward.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, vp]
+    lib.film_interpolate.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, fp, ctypes.c_int, vp]
     lib.film_set_option.argtypes = [vp, cp, ctypes.c_int64]
     lib.film_profile_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, i64p]
     lib.film_plan_json.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, i64p]
@@ -193,6 +196,29 @@ class FilmEngine:
         self._check(self._lib.film_forward(self._h, ctypes.c_void_p(x0_ptr), ctypes.c_void_p(x1_ptr), b, h, w,
                                            ctypes.c_void_p(out_ptr), FILM_MEM_DEVICE,
                                            ctypes.c_void_p(stream) if stream else None))
+
+    def interpolate_frames(self, x0: np.ndarray, x1: np.ndarray, align: Optional[int] = None,
+                           block_shape=None) -> np.ndarray:
+        """Interpolator.__call__ semantics in one C-ABI call (film_interpolate): pad to `align`, optional
+        block_shape = (bh, bw) tiling with per-patch padding, crop, stitch - all on the device."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float32)
+        x1 = np.ascontiguousarray(x1, dtype=np.float32)
+        if x0.ndim != 4 or x0.shape[3] != 3 or x0.shape != x1.shape:
+            raise ValueError(f'expected two [B,H,W,3] arrays of equal shape, got {x0.shape} and {x1.shape}')
+        b, h, w, _ = x0.shape
+        bh, bw = (int(block_shape[0]), int(block_shape[1])) if block_shape else (1, 1)
+        out = np.empty_like(x0)
+        self._check(self._lib.film_interpolate(self._h, x0.ctypes.data, x1.ctypes.data, b, h, w, int(align or 0),
+                                               bh, bw, out.ctypes.data, FILM_MEM_HOST, None))
+        return out
+
+    def interpolate_frames_device(self, x0_ptr: int, x1_ptr: int, b: int, h: int, w: int, out_ptr: int,
+                                  align: Optional[int] = None, block_shape=None, stream: Optional[int] = None) -> None:
+        """Device-resident film_interpolate: raw device pointers, asynchronous on `stream`."""
+        bh, bw = (int(block_shape[0]), int(block_shape[1])) if block_shape else (1, 1)
+        self._check(self._lib.film_interpolate(self._h, ctypes.c_void_p(x0_ptr), ctypes.c_void_p(x1_ptr), b, h, w,
+                                               int(align or 0), bh, bw, ctypes.c_void_p(out_ptr), FILM_MEM_DEVICE,
+                                               ctypes.c_void_p(stream) if stream else None))
 
     def set_option(self, key: str, value: int) -> None:
         self._check(self._lib.film_set_option(self._h, key.encode(), int(value)))

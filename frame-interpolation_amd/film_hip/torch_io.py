@@ -1,8 +1,9 @@
 """Device-resident plumbing around the engine: PyTorch-ROCm tensors for memory and streams only.
 
-The arithmetic of the hot path is entirely inside libfilm_hip.so; torch is used here to hold frames
-in HBM, to pad / crop / (un)fold patches on the device (pure data movement, the same rules as
-eval/interpolator.py) and to hand raw pointers + the current stream to ``film_forward``.
+The hot path is entirely inside libfilm_hip.so (film_interpolate: pad / patch / model / crop / stitch);
+torch is used here only to hold frames in HBM and to hand raw pointers + the current stream to the C-ABI.
+pad_to_align / image_to_patches / patches_to_image below are torch restatements of the reference's layout
+rules, kept for tests and for callers that want the patches themselves.
 """
 from __future__ import annotations
 
@@ -54,26 +55,23 @@ class DeviceInterpolator:
         self._align = align or None
         self._block_shape = block_shape or None
 
-    def interpolate(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
+    def _run(self, x0: torch.Tensor, x1: torch.Tensor, block_shape) -> torch.Tensor:
         assert x0.is_cuda and x0.dtype == torch.float32 and x0.shape == x1.shape and x0.shape[-1] == 3
-        box = None
-        if self._align is not None:
-            x0, box = pad_to_align(x0, self._align)
-            x1, _ = pad_to_align(x1, self._align)
         x0 = x0.contiguous()
         x1 = x1.contiguous()
         b, h, w, _ = x0.shape
         out = torch.empty_like(x0)
         stream = torch.cuda.current_stream(x0.device).cuda_stream
-        self._engine.forward_device(x0.data_ptr(), x1.data_ptr(), b, h, w, out.data_ptr(), stream)
-        if box is not None:
-            oy, ox, th, tw = box
-            out = out[:, oy:oy + th, ox:ox + tw, :]
+        self._engine.interpolate_frames_device(x0.data_ptr(), x1.data_ptr(), b, h, w, out.data_ptr(),
+                                               align=self._align, block_shape=block_shape, stream=stream)
         return out
+
+    def interpolate(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
+        """Interpolator.interpolate (eval/interpolator.py:152-176): pad to align, model, crop - inside
+        film_interpolate (HIP kernels read these tensors and write the result tensor directly)."""
+        return self._run(x0, x1, None)
 
     def __call__(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
         if self._block_shape is not None and self._block_shape[0] * self._block_shape[1] > 1:
-            p0 = image_to_patches(x0, self._block_shape)
-            p1 = image_to_patches(x1, self._block_shape)
-            return patches_to_image(self.interpolate(p0, p1).contiguous(), self._block_shape)
-        return self.interpolate(x0, x1).contiguous()
+            return self._run(x0[:1], x1[:1], self._block_shape)
+        return self._run(x0, x1, None)

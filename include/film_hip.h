@@ -99,12 +99,29 @@ int film_import_packed(film_t* h, const float* src, int64_t n_floats, int mem_ki
 int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out,
                  int mem_kind, void* stream);
 
+/* Interpolator.__call__ on the device (eval/interpolator.py:178-209), frames x0, x1 [B,H,W,3] -> out [B,H,W,3]:
+ *   block_h * block_w <= 1 : zero-pad H, W up to multiples of `align` (offset pad//2, _pad_to_align :30-63), run the
+ *                            model, crop (Interpolator.interpolate :152-176);
+ *   block_h * block_w  > 1 : B must be 1; split the frame into block_h x block_w row-major patches (image_to_patches
+ *                            :66-99, same divisibility asserts), pad EACH patch to `align`, run all patches as one
+ *                            batch (the reference loops over them with B = 1, :199-206), crop each, stitch
+ *                            (patches_to_image :102-126).
+ * align <= 0 means no padding (the reference's align=None); H, W (or the patch) must then be divisible by
+ * 2^(pyramid_levels-1).  Pad / patch / crop / stitch are two HIP kernels that read the caller's frames and write
+ * the plan's input buffer directly (and back), so with FILM_MEM_DEVICE nothing but the frames themselves is copied.
+ * Batches whose activation buffers would exceed 4 GiB are processed in chunks of tiles (results unchanged).
+ * `stream` and mem_kind as for film_forward. */
+int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, int W, int align, int block_h,
+                     int block_w, float* out, int mem_kind, void* stream);
+
 /* Execution options.  Keys:
  *   "autotune" 0/1 time every distinct conv shape of a new plan with each fitting tile shape and keep
  *                  the fastest (default 1; cannot change results - same k-ordered fma chain per output)
  *   "graph"   0/1  replay the plan as a hipGraph (default 1)
  *   "profile" 0/1  record a hipEvent pair around every kernel of the next forwards
- *                  (forces graph off); read the result with film_profile_json        */
+ *                  (forces graph off); read the result with film_profile_json
+ *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in
+ *                  4 GiB-per-activation-buffer limit); frame pairs are independent, results do not change */
 int film_set_option(film_t* h, const char* key, int64_t value);
 
 /* Per-kernel-class timing of the last profiled forward as JSON

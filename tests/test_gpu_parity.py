@@ -168,6 +168,34 @@ def test_device_path_equals_host_path(published):
     assert np.array_equal(dev.cpu().numpy(), host)
 
 
+def test_film_interpolate_equals_numpy_pad_patch_path(published):
+    """film_interpolate (pad / patch / crop / stitch as HIP kernels) vs the reference's layout helpers in numpy
+    around film_forward: bit-identical, untiled B = 2 with odd padding and tiled with per-patch padding."""
+    from eval.interpolator import _pad_to_align, _crop_to_bounding_box, image_to_patches, patches_to_image
+    opt, w, eng = published
+    x0, x1 = _pair(2, 70, 101, seed=29)                      # pads to 128 x 128, offsets (29, 13)
+    p0, box = _pad_to_align(x0, 64)
+    p1, _ = _pad_to_align(x1, 64)
+    assert (box['offset_height'], box['offset_width']) == (29, 13)
+    want = _crop_to_bounding_box(eng.forward(p0, p1), **box)
+    assert np.array_equal(eng.interpolate_frames(x0, x1, align=64), want)
+    x0, x1 = _pair(1, 3 * 50, 2 * 90, seed=31)               # 3 x 2 patches of 50 x 90 -> 64 x 128
+    q0, box = _pad_to_align(image_to_patches(x0, [3, 2]), 64)
+    q1, _ = _pad_to_align(image_to_patches(x1, [3, 2]), 64)
+    want = patches_to_image(_crop_to_bounding_box(eng.forward(q0, q1), **box), [3, 2])
+    got = eng.interpolate_frames(x0, x1, align=64, block_shape=[3, 2])
+    assert np.array_equal(got, want)
+    # chunked batches (the 4 GiB-per-buffer rule, forced small here) do not change a bit
+    eng.set_option('max_batch', 4)
+    assert np.array_equal(eng.interpolate_frames(x0, x1, align=64, block_shape=[3, 2]), want)
+    eng.set_option('max_batch', 1)
+    one = np.concatenate([eng.forward(q0[i:i + 1], q1[i:i + 1]) for i in range(6)], axis=0)
+    eng.set_option('max_batch', 0)
+    assert np.array_equal(one, eng.forward(q0, q1))
+    with pytest.raises(Exception):
+        eng.interpolate_frames(x0, x1, align=64, block_shape=[4, 2])   # 150 % 4 != 0
+
+
 def test_errors(published):
     from film_hip.engine import FilmError
     opt, w, eng = published
