@@ -824,6 +824,36 @@ int copy_out_string(film_t* h, const std::string& s, char* buf, int64_t cap, int
 // =============================================================================================
 extern "C" {
 
+// CRC-32C (Castagnoli, reflected polynomial 0x82F63B78), slicing-by-8.  Host-side helper of the SavedModel
+// variables reader (film_hip/tf_bundle.py): TensorFlow stores a masked crc32c per tensor and per index block.
+uint32_t film_crc32c(uint32_t crc, const void* data, int64_t n) {
+  static uint32_t tab[8][256];
+  static bool init = false;
+  if (!init) {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? (c >> 1) ^ 0x82F63B78u : c >> 1;
+      tab[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int t = 1; t < 8; ++t) tab[t][i] = (tab[t - 1][i] >> 8) ^ tab[0][tab[t - 1][i] & 0xFF];
+    init = true;
+  }
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  uint32_t c = ~crc;
+  while (n > 0 && (reinterpret_cast<uintptr_t>(p) & 7)) { c = tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8); --n; }
+  while (n >= 8) {
+    uint64_t v;
+    memcpy(&v, p, 8);
+    v ^= c;
+    c = tab[7][v & 0xFF] ^ tab[6][(v >> 8) & 0xFF] ^ tab[5][(v >> 16) & 0xFF] ^ tab[4][(v >> 24) & 0xFF] ^
+        tab[3][(v >> 32) & 0xFF] ^ tab[2][(v >> 40) & 0xFF] ^ tab[1][(v >> 48) & 0xFF] ^ tab[0][(v >> 56) & 0xFF];
+    p += 8; n -= 8;
+  }
+  while (n-- > 0) c = tab[0][(c ^ *p++) & 0xFF] ^ (c >> 8);
+  return ~c;
+}
+
 const char* film_version(void) { return "gfx950;film_hip r1"; }
 
 int film_default_config(film_config* cfg) {

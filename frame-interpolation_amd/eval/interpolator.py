@@ -112,7 +112,7 @@ class Interpolator:
     """
     self._options = options or PUBLISHED
     if weights is None:
-      weights = weights_lib.load_weights(model_path)
+      weights = weights_lib.load_weights(model_path, self._options)
     weights_lib.validate_weights(weights, self._options)
     self._engine = FilmEngine(self._options, device=device)
     self._engine.set_weights(weights)

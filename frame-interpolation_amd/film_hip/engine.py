@@ -44,7 +44,7 @@ EXPORTED_SYMBOLS = (
     'film_default_config', 'film_create', 'film_destroy', 'film_last_error', 'film_set_weight',
     'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_forward',
     'film_interpolate',
-    'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_version')
+    'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version')
 
 _lib = None
 
@@ -87,6 +87,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_profile_json.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, i64p]
     lib.film_plan_json.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, i64p]
     lib.film_get_tap.argtypes = [vp, cp, fp, ctypes.c_int64, i64p]
+    lib.film_crc32c.argtypes = [ctypes.c_uint32, vp, ctypes.c_int64]
+    lib.film_crc32c.restype = ctypes.c_uint32
     lib.film_version.argtypes = []
     lib.film_version.restype = cp
     for name in EXPORTED_SYMBOLS:

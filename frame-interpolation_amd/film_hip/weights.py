@@ -143,7 +143,7 @@ def save_weights(model_path: str, weights: Dict[str, np.ndarray]) -> str:
     return fn
 
 
-def load_weights(model_path: str) -> Dict[str, np.ndarray]:
+def load_weights(model_path: str, opt: Options = PUBLISHED) -> Dict[str, np.ndarray]:
     """Loads the weight set of a model directory.
 
     ``model_path`` plays the role of the SavedModel directory passed to
@@ -159,6 +159,6 @@ def load_weights(model_path: str) -> Dict[str, np.ndarray]:
     idx = os.path.join(model_path, 'variables', 'variables.index')
     if os.path.isfile(idx):
         from . import tf_bundle
-        return tf_bundle.load_film_weights(os.path.join(model_path, 'variables', 'variables'))
+        return tf_bundle.load_film_weights(os.path.join(model_path, 'variables', 'variables'), opt)
     raise FileNotFoundError(
         f'{model_path}: neither {WEIGHTS_FILE} nor a SavedModel variables bundle found')

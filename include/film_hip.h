@@ -139,6 +139,11 @@ int film_plan_json(film_t* h, int B, int H, int W, char* buf, int64_t capacity, 
  * models/film_net/interpolator.py:191-199. */
 int film_get_tap(film_t* h, const char* name, float* dst, int64_t capacity_floats, int64_t dims[4]);
 
+/* CRC-32C (Castagnoli) continued from `crc` (0 to start) over n bytes.  Host helper of the TF-free SavedModel
+ * variables reader (frame-interpolation_amd/film_hip/tf_bundle.py), which checks the masked crc32c TensorFlow
+ * stores per tensor and per index block; part of replacing tf.saved_model.load (eval/interpolator.py:148). */
+uint32_t film_crc32c(uint32_t crc, const void* data, int64_t n);
+
 /* Library build info: "gfx950;<build id>" */
 const char* film_version(void);
 

@@ -1,0 +1,116 @@
+"""TF-free SavedModel variables reader (film_hip/tf_bundle.py): format known answers, round trips through the
+writer, corruption detection, key mapping rules.  No TensorFlow checkpoint is reachable from this environment,
+so the reader is pinned to the published format constants and to its own writer, not to a real bundle."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+
+def test_crc32c_known_answers():
+    from film_hip import tf_bundle as tb
+    # RFC 3720 B.4 test vectors
+    assert tb._crc32c_py(b'123456789') == 0xE3069283
+    assert tb._crc32c_py(bytes(32)) == 0x8A9136AA
+    assert tb._crc32c_py(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert tb._crc32c_py(bytes(range(32))) == 0x46DD794E
+    big = np.random.default_rng(0).integers(0, 256, 100003, dtype=np.uint8)
+    assert tb.crc32c(big) == tb._crc32c_py(big.tobytes())             # native slicing-by-8 vs table
+    assert tb.crc32c(big[5:]) == tb._crc32c_py(big[5:].tobytes())     # unaligned start
+    half = tb.crc32c(big[:50000])
+    assert tb.crc32c(big[50000:], half) == tb.crc32c(big)             # continuation
+    # leveldb mask: rotate right 15, add 0xa282ead8
+    assert tb.unmask_crc(tb.mask_crc(0xE3069283)) == 0xE3069283
+    assert tb.mask_crc(0) == 0xa282ead8
+
+
+def test_table_roundtrip_many_blocks(tmp_path):
+    from film_hip import tf_bundle as tb
+    rng = np.random.default_rng(1)
+    items = [(f'layer/{i:04d}/kernel'.encode(), rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8).tobytes())
+             for i in range(500)]
+    items.append((b'', b'header'))
+    fn = str(tmp_path / 't.index')
+    tb.write_table(fn, items, block_size=512)
+    got = tb.read_table(fn)
+    assert got == sorted(items)
+    raw = open(fn, 'rb').read()
+    assert struct.unpack('<Q', raw[-8:])[0] == 0xdb4775248b80fb57
+    bad = bytearray(raw)
+    bad[100] ^= 1
+    open(fn, 'wb').write(bad)
+    with pytest.raises(ValueError, match='crc32c'):
+        tb.read_table(fn)
+    assert len(tb.read_table(fn, verify=False)) == len(items)
+    open(fn, 'wb').write(raw[:-1] + b'\x00')
+    with pytest.raises(ValueError, match='magic'):
+        tb.read_table(fn)
+
+
+def test_film_bundle_roundtrip_and_interpolator_load_path(tmp_path, tiny_weights):
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    model_dir = str(tmp_path / 'saved_model')
+    prefix = tb.save_film_bundle(model_dir, tiny_weights, TINY)
+    assert os.path.isfile(prefix + '.index') and os.path.isfile(prefix + '.data-00000-of-00001')
+    report = {}
+    got = tb.load_film_weights(prefix, TINY, report=report)
+    assert set(got) == set(tiny_weights)
+    for k in tiny_weights:
+        assert np.array_equal(got[k], tiny_weights[k]), k
+    assert all(rule == 'path' for rule, _ in report.values())
+    # same directory through the loader Interpolator(model_path) uses
+    via = W.load_weights(model_dir, TINY)
+    W.validate_weights(via, TINY)
+    rd = tb.BundleReader(prefix)
+    og = rd.object_graph_keys()
+    assert len(og) == len(tiny_weights) and all(k.endswith(tb.VAR_SUFFIX) for k in og)
+    # a flipped payload byte is caught by the per-tensor crc
+    fn = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(fn, 'rb').read())
+    raw[10] ^= 0x40
+    open(fn, 'wb').write(raw)
+    with pytest.raises(ValueError, match='crc32c'):
+        tb.load_film_weights(prefix, TINY)
+
+
+def test_published_keys_and_shared_predictor_aliases():
+    from film_hip import tf_bundle as tb
+    from film_hip.options import PUBLISHED
+    s = PUBLISHED.specialized_levels
+    assert tb.canonical_name('layer_with_weights-0/extract_sublevels/convs/7/kernel', s) == \
+        'feat_net/sub_extractor/cfeat_conv_7/kernel'
+    assert tb.canonical_name('layer_with_weights-1/_predictors/1/_convs/4/bias', s) == \
+        'predict_flow/flow_predictor_1/conv_4/bias'
+    for p in (3, 4, 5, 6):   # the shared predictor is reachable as _predictors[3..6] (pyramid_flow_estimator.py:118-123)
+        assert tb.canonical_name(f'x/_predictors/{p}/_convs/0/kernel', s) == 'predict_flow/flow_predictor_shared/conv_0/kernel'
+    assert tb.canonical_name('layer_with_weights-2/convs/3/1/kernel', s) == 'fusion/convs_3_1/kernel'
+    assert tb.canonical_name('layer_with_weights-2/output_conv/bias', s) == 'fusion/output_conv/bias'
+    assert tb.canonical_name('optimizer/iter', s) is None
+    for name in ('feat_net/sub_extractor/cfeat_conv_3/kernel', 'predict_flow/flow_predictor_shared/conv_2/bias',
+                 'fusion/convs_2_0/kernel', 'fusion/output_conv/kernel'):
+        key = tb.checkpoint_key(name, PUBLISHED)
+        assert tb.canonical_name(key[:-len(tb.VAR_SUFFIX)], s) == name
+
+
+def test_shape_fallback_when_paths_are_unknown(tmp_path, tiny_weights):
+    """Keys that follow no known attribute path: tensors are placed by shape in natural key order."""
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    names = [n for spec, _, _ in W.weight_specs(TINY) for n in (spec + '/kernel', spec + '/bias')]
+    tensors = {f'model/variables/{i}{tb.VAR_SUFFIX}': tiny_weights[n] for i, n in enumerate(names)}
+    tensors['optimizer/iter' + tb.VAR_SUFFIX] = np.zeros((), np.float32)
+    prefix = str(tmp_path / 'variables' / 'variables')
+    tb.write_bundle(prefix, tensors, object_graph=False)
+    report = {}
+    got = tb.load_film_weights(prefix, TINY, report=report)
+    assert all(rule == 'shape' for rule, _ in report.values())
+    for n in names:
+        assert np.array_equal(got[n], tiny_weights[n]), n
+    del tensors[f'model/variables/0{tb.VAR_SUFFIX}']
+    tb.write_bundle(prefix, tensors, object_graph=False)
+    with pytest.raises(KeyError):
+        tb.load_film_weights(prefix, TINY)
