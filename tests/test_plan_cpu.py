@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     from film_hip import engine
     lib = engine.load_library()
     header = open(os.path.join(ROOT, 'include', 'film_hip.h')).read()
-    declared = set(re.findall(r'^(?:int|void|const char\*)\s+(film_[a-z_0-9]+)\s*\(', header, flags=re.M))
+    declared = set(re.findall(r'^(?:int|void|uint32_t|const char\*)\s+(film_[a-z_0-9]+)\s*\(', header, flags=re.M))
     assert declared == set(engine.EXPORTED_SYMBOLS), declared ^ set(engine.EXPORTED_SYMBOLS)
     for sym in declared:
         assert getattr(lib, sym) is not None
