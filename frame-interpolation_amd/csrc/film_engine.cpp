@@ -1087,7 +1087,6 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
   if (mem_kind != FILM_MEM_HOST && mem_kind != FILM_MEM_DEVICE) return fail(h, FILM_ERR_INVALID, "bad mem_kind");
   if (B < 1 || H < 1 || W < 1) return fail(h, FILM_ERR_INVALID, "B, H, W must be positive");
   const int bh = block_h > 0 ? block_h : 1, bw = block_w > 0 ? block_w : 1;
-  if (bh * bw > 1 && B != 1) return fail(h, FILM_ERR_INVALID, "the tiled path takes one frame pair (eval/interpolator.py:192-206)");
   // the reference's asserts (eval/interpolator.py:84-89), same messages
   if (H % bh) return fail(h, FILM_ERR_INVALID, "block_height=%d should evenly divide height=%d.", bh, H);
   if (W % bw) return fail(h, FILM_ERR_INVALID, "block_width=%d should evenly divide width=%d.", bw, W);

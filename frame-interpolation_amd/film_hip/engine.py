@@ -247,6 +247,28 @@ class FilmEngine:
         self._check(self._lib.film_get_tap(self._h, name.encode(), out.ctypes.data, out.size, dims))
         return out
 
+    def forward_with_aux(self, x0: np.ndarray, x1: np.ndarray) -> Dict[str, object]:
+        """The reference model's output dictionary with `use_aux_outputs` on (models/film_net/interpolator.py:
+        188-199): 'image', 'x0_warped', 'x1_warped' and the four flow pyramids (lists, finest level first), read
+        back from the workspace of this forward.  H, W must already be divisible by 2^(pyramid_levels-1)."""
+        from . import weights as W
+        image = self.forward(x0, x1)
+        b = image.shape[0]
+        opt = self.options
+        c0 = W.feature_channels(opt)[0]
+        aligned0 = self.tap('aligned0')
+        res = [self.tap(f'res{l}') for l in range(opt.pyramid_levels)]
+        flow = [self.tap(f'v{l}') if l < opt.pyramid_levels - 1 else res[l] for l in range(opt.fusion_pyramid_levels)]
+        return {
+            'image': image,
+            'x0_warped': np.ascontiguousarray(aligned0[..., 2 * c0:2 * c0 + 3]),
+            'x1_warped': np.ascontiguousarray(aligned0[..., 2 * c0 + 3:2 * c0 + 6]),
+            'forward_residual_flow_pyramid': [r[:b] for r in res],
+            'backward_residual_flow_pyramid': [r[b:] for r in res],
+            'forward_flow_pyramid': [f[:b] for f in flow],
+            'backward_flow_pyramid': [f[b:] for f in flow],
+        }
+
     @staticmethod
     def version() -> str:
         return load_library().film_version().decode()

@@ -71,6 +71,11 @@ class DeviceInterpolator:
         film_interpolate (HIP kernels read these tensors and write the result tensor directly)."""
         return self._run(x0, x1, None)
 
+    def batch(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
+        """Extension: Interpolator.__call__ applied to every pair of a batch (tiled or not) in one call."""
+        bs = self._block_shape
+        return self._run(x0, x1, bs if bs is not None and bs[0] * bs[1] > 1 else None)
+
     def __call__(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
         if self._block_shape is not None and self._block_shape[0] * self._block_shape[1] > 1:
             return self._run(x0[:1], x1[:1], self._block_shape)

@@ -102,10 +102,12 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
 /* Interpolator.__call__ on the device (eval/interpolator.py:178-209), frames x0, x1 [B,H,W,3] -> out [B,H,W,3]:
  *   block_h * block_w <= 1 : zero-pad H, W up to multiples of `align` (offset pad//2, _pad_to_align :30-63), run the
  *                            model, crop (Interpolator.interpolate :152-176);
- *   block_h * block_w  > 1 : B must be 1; split the frame into block_h x block_w row-major patches (image_to_patches
+ *   block_h * block_w  > 1 : split every frame into block_h x block_w row-major patches (image_to_patches
  *                            :66-99, same divisibility asserts), pad EACH patch to `align`, run all patches as one
  *                            batch (the reference loops over them with B = 1, :199-206), crop each, stitch
- *                            (patches_to_image :102-126).
+ *                            (patches_to_image :102-126).  The reference's tiled path takes one frame pair; B > 1
+ *                            here tiles every pair of the batch the same way (used by the breadth-first
+ *                            recursion driver, film_hip/recursive.py).
  * align <= 0 means no padding (the reference's align=None); H, W (or the patch) must then be divisible by
  * 2^(pyramid_levels-1).  Pad / patch / crop / stitch are two HIP kernels that read the caller's frames and write
  * the plan's input buffer directly (and back), so with FILM_MEM_DEVICE nothing but the frames themselves is copied.

@@ -196,6 +196,43 @@ def test_film_interpolate_equals_numpy_pad_patch_path(published):
         eng.interpolate_frames(x0, x1, align=64, block_shape=[4, 2])   # 150 % 4 != 0
 
 
+def test_breadth_first_device_recursion_equals_reference_order(published):
+    """film_hip.recursive (one batched call per depth, frames resident in HBM) vs the reference's depth-first
+    generator through the numpy Interpolator (eval/util.py:62-91): same frames, same order, same bits."""
+    import torch
+    from eval import util
+    from eval.interpolator import Interpolator
+    from film_hip.recursive import interpolate_recursively
+    from film_hip.torch_io import DeviceInterpolator
+    opt, w, eng = published
+    rng = np.random.default_rng(37)
+    frames = [rng.random((72, 100, 3), dtype=np.float32) for _ in range(3)]
+    host_it = Interpolator('', align=64, block_shape=[2, 2], weights=w)
+    want = list(util.interpolate_recursively_from_memory(frames, 2, host_it))
+    dev_it = DeviceInterpolator(eng, align=64, block_shape=[2, 2])
+    got = [f.cpu().numpy() for f in interpolate_recursively([torch.from_numpy(f).cuda() for f in frames], 2, dev_it)]
+    assert len(got) == len(want) == 2 * 4 + 1
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
+
+
+def test_aux_outputs_match_oracle(published):
+    """FilmEngine.forward_with_aux = the reference model's use_aux_outputs dictionary (interpolator.py:188-199)."""
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    x0, x1 = _pair(2, 64, 128, seed=41)
+    got = eng.forward_with_aux(x0, x1)
+    want_img, aux = fo.film_forward(x0, x1, w, fo.Options(), return_aux=True)
+    assert np.abs(got['image'] - want_img).max() < IMAGE_TOL
+    assert np.abs(got['x0_warped'] - aux['x0_warped']).max() < FEATURE_TOL
+    assert np.abs(got['x1_warped'] - aux['x1_warped']).max() < FEATURE_TOL
+    for name in ('forward_residual_flow_pyramid', 'backward_residual_flow_pyramid', 'forward_flow_pyramid',
+                 'backward_flow_pyramid'):
+        assert len(got[name]) == len(aux[name])
+        for a, b in zip(got[name], aux[name]):
+            assert a.shape == b.shape and np.abs(a - b).max() < FLOW_TOL, name
+
+
 def test_errors(published):
     from film_hip.engine import FilmError
     opt, w, eng = published
