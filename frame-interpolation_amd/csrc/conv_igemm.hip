@@ -15,13 +15,16 @@
 //     bank-conflict free (MI355X_MICROARCH.md, LDS table: rows distinct mod 16 per 16-lane group).
 //   * the epilogue adds the bias, applies leaky_relu and stores 128-byte rows into the channel slice
 //     of the destination buffer (the consumer's concat input).
-// Two kernel templates:
-//   conv_buf_impl.h    the production kernel: buffer loads with hardware zero fill, K-major weights, no vector
+// Three kernel templates:
+//   conv_halo_impl.h   3x3 convs with deep K: the activation halo patch is staged once per 16-channel chunk and the
+//                      nine taps run out of LDS (6.8x fewer A loads / LDS stores, less L2 traffic, higher clocks).
+//   conv_buf_impl.h    the general kernel: buffer loads with hardware zero fill, K-major weights, no vector
 //                      instruction per K-step besides loads, LDS traffic and MFMAs.
 //   conv_igemm_impl.h  the first-generation kernel (64-bit pointers, select-based zero fill, [K][N] weights);
 //                      still runs the 3-channel first layer (its 4-taps-per-step mode) and is the A/B baseline
 //                      of tools/conv_bench.hip.
 #include "conv_buf_impl.h"
+#include "conv_halo_impl.h"
 #include "conv_igemm_impl.h"
 
 template <int F>
@@ -50,10 +53,27 @@ static hipError_t launch_c3(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+template <int F>
+static hipError_t launch_halo(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case HALO_8x128: return conv_halo_launch<8, 128, 4, 2, F>(p, s);
+    case HALO_8x64: return conv_halo_launch<8, 64, 4, 1, F>(p, s);
+    case HALO_8x32: return conv_halo_launch<8, 32, 4, 1, F>(p, s);
+    case HALO_4x64: return conv_halo_launch<4, 64, 4, 1, F>(p, s);
+    case HALO_4x128: return conv_halo_launch<4, 128, 2, 2, F>(p, s);
+    case HALO_4x32: return conv_halo_launch<4, 32, 4, 1, F>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
+  if (tile & CONV_TILE_HALO) {
+    if (p.ksize != 3) return hipErrorInvalidValue;
+    return (tile & CONV_TILE_XCD) ? launch_halo<CONV_B_XCD_M>(p, shape, s) : launch_halo<0>(p, shape, s);
+  }
   if (tile & CONV_TILE_C3)
     return (tile & CONV_TILE_XCD) ? launch_c3<CONV_F_XCD_M>(p, shape, s) : launch_c3<0>(p, shape, s);
   return (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);

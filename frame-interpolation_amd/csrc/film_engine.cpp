@@ -65,6 +65,8 @@ struct OpDesc {
   int c3 = 0;                         // first-layer mode of the conv kernel (3-channel image input)
   int64_t w_off = 0, b_off = 0;
   int64_t w2_off = 0, b2_off = 0;     // flow_head: second 1x1 conv
+  int64_t wh_off = -1;                // conv: the layer's conv_halo_kernel weight copy (-1: none)
+  int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
@@ -83,6 +85,8 @@ struct LayerPack {
   // [Cout][kh*kw*ctot] with k = tap*ctot + channel; the 1x1 heads keep [ctot][Cout]
   bool kmajor() const { return !c3 && cout % 32 == 0; }
   int64_t w_off = 0, b_off = 0;
+  int64_t wh_off = -1;       // 3x3 K-major layers: second copy packed for conv_halo_kernel, [Cout][ctot/16][9][16]
+  bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
   int ctot() const { return (int)perm.size(); }
   int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
 };
@@ -276,6 +280,8 @@ void build_layers(film_t* h) {
     L.b_off = off;
     off += L.cout;
     off = (off + 3) & ~int64_t(3);
+    if (L.has_halo()) { L.wh_off = off; off += L.packed_rows() * L.cout; }
+    off = (off + 3) & ~int64_t(3);
   }
   h->packed_floats = off;
 }
@@ -329,6 +335,10 @@ struct Planner {
     return shape | CONV_TILE_XCD;
   }
 
+  static int choose_halo_tile(int Cout) {
+    return (Cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_HALO | CONV_TILE_XCD;
+  }
+
   void conv(const std::string& tag, const std::string& layer, std::vector<SegDesc> segs, View out, int NB, int H,
             int W, bool leaky) {
     const LayerPack& L = h->layers[h->layer_idx.at(layer)];
@@ -343,10 +353,17 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off;
     op.out = out; op.NB = NB; op.H = H; op.W = W;
     const int64_t M = (int64_t)NB * H * W;
-    op.tile = choose_tile(M, L.cout);
+    // Kernel family by layer shape only (never by timing, and not by the batch size): the two kernels sum K in a
+    // different order, so the choice must be a pure function of the layer for results to be reproducible across
+    // batch sizes and runs.  Halo staging pays where K is deep (traffic bound) or N is too narrow to amortise the
+    // per-tap A gather; measured in tools/conv_bench.hip.
+    bool any_up = false;
+    for (int i = 0; i < op.nseg; ++i) any_up |= segs[i].up != 0;
+    op.halo = L.has_halo() && !any_up && W >= 24 && H >= 4 && (ctot >= 512 || L.cout == 32);
+    op.tile = op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
     P->ops.push_back(op);
@@ -574,7 +591,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].C = op.seg[i].v.C;
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
-      p.ksize = op.ksize; p.w = wts + op.w_off; p.bias = wts + op.b_off;
+      p.ksize = op.ksize; p.w = wts + ((op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off); p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
       p.M = op.NB * op.H * op.W;
@@ -629,6 +646,16 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
   return hipErrorInvalidValue;
 }
 
+std::vector<int> halo_candidates(int Cout) {
+  std::vector<int> shapes;
+  if (Cout % 128 == 0) shapes = {HALO_4x64, HALO_4x128, HALO_8x64, HALO_8x128};
+  else if (Cout % 64 == 0) shapes = {HALO_4x64, HALO_8x64, HALO_4x32, HALO_8x32};
+  else shapes = {HALO_8x32, HALO_4x32};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_HALO); out.push_back(sh | CONV_TILE_HALO | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> tile_candidates(int Cout) {
   std::vector<int> shapes;
   if (Cout % 128 == 0) shapes = {TILE_128x128, TILE_256x128, TILE_256x64, TILE_128x64, TILE_64x64};
@@ -641,7 +668,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -667,7 +694,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = tile_candidates(op.Cout);
+      std::vector<int> cands = op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -781,7 +808,7 @@ std::string plan_json(film_t* h, const Plan& P) {
   for (size_t i = 0; i < h->layers.size(); ++i) {
     const LayerPack& L = h->layers[i];
     o << (i ? "," : "") << "{\"name\":\"" << L.name << "\",\"kh\":" << L.kh << ",\"kw\":" << L.kw << ",\"cin\":" << L.cin
-      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << "}";
+      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << "}";
   }
   o << "],\"ops\":[";
   for (size_t i = 0; i < P.ops.size(); ++i) {
@@ -789,7 +816,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
       << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
     json_view(o, "in", op.in, P); o << ",";
@@ -972,6 +999,18 @@ int film_finalize(film_t* h) {
         if (ref < 0) continue;  // zero row (padding channel)
         memcpy(dst + ((size_t)tap * ct + ci) * L.cout, src + ((size_t)tap * L.cin + ref) * L.cout, sizeof(float) * L.cout);
       }
+    if (L.wh_off >= 0) {  // [Cout][chunk][tap][16] copy for conv_halo_kernel
+      float* dh = h->packed_host.data() + L.wh_off;
+      const size_t nkc = (size_t)ct / 16;
+      for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < ct; ++ci) {
+          const int ref = L.perm[ci];
+          if (ref < 0) continue;
+          const float* row = src + ((size_t)tap * L.cin + ref) * L.cout;
+          float* col = dh + ((size_t)(ci / 16) * 9 + tap) * 16 + ci % 16;
+          for (int co = 0; co < L.cout; ++co) col[(size_t)co * nkc * 144] = row[co];
+        }
+    }
     memcpy(h->packed_host.data() + L.b_off, bw->second.data.data(), sizeof(float) * L.cout);
   }
   int rc = upload_packed(h);

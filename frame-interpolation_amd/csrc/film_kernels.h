@@ -29,7 +29,7 @@ struct ConvParams {
   int nseg;
   int ksize;          // 1, 2, 3; TF 'same': pad_before = (ksize-1)/2, rest after
   const float* w;     // conv_buf_kernel: packed [Cout][ksize*ksize*Ctot] (K contiguous per output channel);
-                      // conv_igemm_kernel: [ksize*ksize*Ctot][Cout] ([48][Cout] in first-layer mode)
+                      // conv_halo_kernel: [Cout][Ctot/16][9][16]; conv_igemm_kernel first-layer mode: [48][Cout]
   const float* bias;  // [Cout]
   float* out;         // [NB][H][W][ostride], first output channel
   int ostride;
@@ -132,7 +132,11 @@ struct TileMapParams {
 // Tile id = shape index + CONV_TILE_XCD when the XCD-contiguous block mapping is used.
 enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
                 TILE_128x64 = 5, TILE_256x128 = 6 /* 8 waves, 4x2 */, TILE_SHAPES = 7, CONV_TILE_XCD = 16,
-                CONV_TILE_C3 = 32 /* first-layer mode: 3-channel image input, [48][Cout] weights */ };
+                CONV_TILE_C3 = 32 /* first-layer mode: 3-channel image input, [48][Cout] weights */,
+                CONV_TILE_HALO = 64 /* conv_halo_kernel: shape index = HaloTile, weights [Cout][chunk][tap][16] */ };
+// conv_halo_kernel tiles: patch rows x 32 pixels x output channels (waves M x N)
+enum HaloTile { HALO_8x128 = 0 /* 4x2 */, HALO_8x64 = 1 /* 4x1 */, HALO_8x32 = 2 /* 4x1 */, HALO_4x64 = 3 /* 4x1 */,
+                HALO_4x128 = 4 /* 2x2 */, HALO_4x32 = 5 /* 4x1 */, HALO_SHAPES = 6 };
 
 struct TileShape { int bm, bn; };
 static inline TileShape film_tile_shape(int tile) {

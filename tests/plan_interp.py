@@ -63,6 +63,13 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             # MFMA-conv layers are packed K-major: [Cout][tap][Ctot]
             wt = packed[op['w_off']:op['w_off'] + ks * ks * ct * co].reshape(co, ks, ks, ct)
             wt = np.ascontiguousarray(wt.transpose(1, 2, 3, 0))
+            if op.get('wh_off', -1) >= 0:
+                # the layer's second copy for conv_halo_kernel, [Cout][chunk][tap][16], must hold the same weights
+                wh = packed[op['wh_off']:op['wh_off'] + 9 * ct * co].reshape(co, ct // 16, 3, 3, 16)
+                wh = wh.transpose(2, 3, 1, 4, 0).reshape(3, 3, ct, co)
+                assert np.array_equal(wh, wt), 'halo weight copy differs'
+                if op.get('halo'):
+                    assert ks == 3 and not any(sg['up'] for sg in op['segs'])
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             _view(arena, op['out'], nb, h, w)[...] = y
