@@ -362,7 +362,9 @@ struct Planner {
     // per-tap A gather; measured in tools/conv_bench.hip.
     bool any_up = false;
     for (int i = 0; i < op.nseg; ++i) any_up |= segs[i].up != 0;
-    op.halo = L.has_halo() && !any_up && W >= 24 && H >= 4 && (ctot >= 512 || L.cout == 32);
+    const int64_t px = (int64_t)H * W;
+    op.halo = L.has_halo() && !any_up && px >= 8192 &&
+              (ctot >= 768 || (ctot >= 512 && px >= 100000) || L.cout == 32);
     op.tile = op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
