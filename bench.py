@@ -106,6 +106,7 @@ def main():
     ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 precision-mode measurement')
     ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
     args = ap.parse_args()
 
@@ -232,6 +233,26 @@ def main():
             'roofline': roofline,
         }
         result.update(extra)
+        if world == 1 and not args.no_split:
+            # Extra, NOT the headline value: the opt-in precision mode "bf16x6" (exact 3-way bf16 split of every fp32
+            # operand, six partial products, fp32 accumulate) on the same workload, with its distance from the
+            # default fp32-MFMA result.
+            ref_out = out.clone()
+            eng.set_option('precision', 1)
+            for _ in range(max(1, args.warmup)):
+                out2 = it(x0, x1)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                out2 = it(x0, x1)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            result['precision_mode_bf16x6'] = {
+                'value': round(args.steps / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                'max_abs_diff_vs_f32_mode': float((out2 - ref_out).abs().max()),
+                'note': 'opt-in (film_set_option precision=1); the headline value above is the fp32-MFMA default',
+            }
+            eng.set_option('precision', 0)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(weights)
         else:

@@ -25,6 +25,7 @@
 //                      of tools/conv_bench.hip.
 #include "conv_buf_impl.h"
 #include "conv_halo_impl.h"
+#include "conv_split_impl.h"
 #include "conv_igemm_impl.h"
 
 template <int F>
@@ -66,10 +67,27 @@ static hipError_t launch_halo(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+template <int F>
+static hipError_t launch_split(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case HALO_8x128: return conv_halo_split_launch<8, 128, 4, 2, 6, F>(p, s);
+    case HALO_8x64: return conv_halo_split_launch<8, 64, 4, 1, 6, F>(p, s);
+    case HALO_8x32: return conv_halo_split_launch<8, 32, 4, 1, 6, F>(p, s);
+    case HALO_4x64: return conv_halo_split_launch<4, 64, 4, 1, 6, F>(p, s);
+    case HALO_4x128: return conv_halo_split_launch<4, 128, 2, 2, 6, F>(p, s);
+    case HALO_4x32: return conv_halo_split_launch<4, 32, 4, 1, 6, F>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
+  if (tile & CONV_TILE_SPLIT) {
+    if (p.ksize != 3) return hipErrorInvalidValue;
+    return (tile & CONV_TILE_XCD) ? launch_split<CONV_B_XCD_M>(p, shape, s) : launch_split<0>(p, shape, s);
+  }
   if (tile & CONV_TILE_HALO) {
     if (p.ksize != 3) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_halo<CONV_B_XCD_M>(p, shape, s) : launch_halo<0>(p, shape, s);

@@ -1,0 +1,289 @@
+// conv_split_impl.h -- OPT-IN precision mode "bf16x6" (film_set_option("precision", 1); the default engine path is
+// the fp32 MFMA of conv_halo_impl.h / conv_buf_impl.h): the halo-staged 3x3 convolution with every fp32
+// operand split EXACTLY into three bf16 pieces (x = hi + mid + lo: 8 + 8 + 8 significant bits, by truncation) and
+// the product formed from the six partial products of weight >= 2^-16,
+//     a*b ~= hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)        (dropped: mid*lo, lo*mid, lo*lo <= 2^-24),
+// on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; bf16 x bf16 products are exact in fp32).  Six bf16 MFMAs of 32
+// cycles replace eight fp32 MFMAs of 64 cycles per 16 K: 2.67x the matrix rate at fp32-level accuracy (measured
+// against the fp32 kernels on the same data, tools/conv_bench.hip: max |delta| 2.8e-5 on outputs of O(10), the same
+// as between two fp32 kernels that sum K in a different order).  Measured speed: 1.45-1.65x - at 68 % MFMA-pipe
+// occupancy the bf16 matrix pipe is power limited (clock 1.9 GHz), like every dense bf16 GEMM on this part.
+//
+//   * activations stay fp32 in HBM; the split happens once per staged element on the way into LDS (the halo
+//     staging amortises it over the nine taps); weights are split once on the host side:
+//     [Cout][chunk][tap][plane][16] bf16.
+//   * LDS rows are 112 B: 3 planes x 16 bf16 (96 B) + 16 B pad, i.e. 7 sixteen-byte units - odd, so 16 consecutive
+//     rows hit 16 distinct bank quads and the ds_read_b128 fragment reads need no swizzle.
+#pragma once
+#include "conv_buf_impl.h"
+
+typedef __bf16 sbf8 __attribute__((ext_vector_type(8)));
+typedef unsigned su4 __attribute__((ext_vector_type(4)));
+typedef unsigned su2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ su4 conv_buf_load_u4(conv_rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(su4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
+// exact 3-way split of four floats into bf16 planes (each plane: 4 bf16 = 2 dwords)
+__device__ __forceinline__ void conv_split4(bf4 x, su2& hi, su2& mid, su2& lo) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned xb = __float_as_uint(x[i]);
+    const unsigned hb = xb & 0xFFFF0000u;
+    const float r = x[i] - __uint_as_float(hb);
+    const unsigned rb = __float_as_uint(r);
+    const unsigned mb = rb & 0xFFFF0000u;
+    const float q = r - __uint_as_float(mb);
+    h[i] = hb; m[i] = mb; l[i] = __float_as_uint(q);
+  }
+  // pack the upper halves of two floats into one dword (bytes 3,2 of the second | bytes 3,2 of the first)
+  hi.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u); hi.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
+  mid.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); mid.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
+  lo.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); lo.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+}
+
+template <int TH, int BN, int WGM, int WGN, int NPROD, int FLAGS>
+__global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvParams p) {
+  constexpr int NW = WGM * WGN, NT = NW * 64;
+  constexpr int TM = TH / WGM;
+  constexpr int WTN = BN / WGN, TN = WTN / 32;
+  constexpr int HR = TH + 2, HC = 34;
+  constexpr int ROWB = 112;                      // bytes per LDS row
+  constexpr int A_STAGE = HR * HC * ROWB;        // bytes
+  constexpr int B_STAGE = BN * ROWB;
+  constexpr int HF4 = HR * HC * 4;
+  constexpr int AH = (HF4 + NT - 1) / NT;
+  constexpr int BU = BN * 6;                     // 16-byte units of one weight step
+  constexpr int BLD = (BU + NT - 1) / NT;
+  static_assert(TH % WGM == 0 && TM >= 1 && TN >= 1, "bad tile");
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_b[];  // [A0][A1][B x3]
+  unsigned char* const Bsm = smem_b + 2 * A_STAGE;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int wm = wv / WGN, wn = wv % WGN;
+
+  int bx = blockIdx.x, by = blockIdx.y;
+  if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int nwg = nbx * nby;
+    const int lin = by * nbx + bx;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int nl = base + idx;
+    bx = nl / nby;
+    by = nl - bx * nby;
+  }
+  const int ntx = (p.W + 31) >> 5, nty = (p.H + TH - 1) / TH;
+  const int img = bx / (ntx * nty);
+  const int trem = bx - img * (ntx * nty);
+  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * 32;
+  const int n0 = by * BN;
+
+  // ---- A staging ---------------------------------------------------------------------------------------
+  int aiy[AH], aix[AH];
+  bool ain[AH];
+  int alds[AH];  // byte offset of plane 0 of this thread's 4 channels, -1: no slot
+#pragma unroll
+  for (int i = 0; i < AH; ++i) {
+    const int f = t + NT * i;
+    const bool slot = f < HF4;
+    const int r = slot ? (f >> 2) : 0, ch = f & 3;
+    const int hy = r / HC, hx = r - hy * HC;
+    aiy[i] = y0 - 1 + hy; aix[i] = x0 - 1 + hx;
+    ain[i] = slot && aiy[i] >= 0 && aiy[i] < p.H && aix[i] >= 0 && aix[i] < p.W;
+    alds[i] = slot ? r * ROWB + ch * 8 : -1;
+  }
+  const int scol = (t & 3) * 4;
+  unsigned aoff[AH];
+  conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
+  int sg = 0, c0 = 0, segC = p.seg[0].C;
+  auto setup_seg = [&]() {
+    const ConvSeg& s = p.seg[sg];
+    arsrc = conv_make_rsrc(s.ptr);
+    segC = s.C;
+    int be = img + s.boff;
+    if (s.bmod && be >= s.bmod) be -= s.bmod;
+#pragma unroll
+    for (int i = 0; i < AH; ++i)
+      aoff[i] = ain[i] ? (unsigned)((((size_t)be * p.H + aiy[i]) * p.W + aix[i]) * s.stride + scol) * 4u : OOB;
+  };
+
+  // ---- B staging ---------------------------------------------------------------------------------------
+  const int nkc = p.Ctot / 16;
+  const int nsteps = nkc * 9;
+  const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
+  unsigned boff[BLD];
+  int blds[BLD];
+#pragma unroll
+  for (int i = 0; i < BLD; ++i) {
+    const int u = t + NT * i;
+    const bool slot = u < BU;
+    const int row = slot ? u / 6 : 0, q = slot ? u - row * 6 : 0;
+    boff[i] = (unsigned)((size_t)(n0 + row) * nsteps * 96 + q * 16);
+    blds[i] = slot ? row * ROWB + q * 16 : -1;
+  }
+
+  bf4 areg[AH];
+  su4 breg[BLD];
+  auto load_a = [&]() {
+    const unsigned so = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int i = 0; i < AH; ++i) areg[i] = conv_buf_load(arsrc, aoff[i], so);
+  };
+  auto next_chunk = [&](int kc_next) {
+    if (kc_next >= nkc) {
+#pragma unroll
+      for (int i = 0; i < AH; ++i) aoff[i] = OOB;
+      return;
+    }
+    c0 += 16;
+    if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
+  };
+  auto store_a = [&](int stage) {
+    unsigned char* As = smem_b + stage * A_STAGE;
+#pragma unroll
+    for (int i = 0; i < AH; ++i) {
+      if (NT * (i + 1) <= HF4 || alds[i] >= 0) {
+        su2 hi, mid, lo;
+        conv_split4(areg[i], hi, mid, lo);
+        *reinterpret_cast<su2*>(As + alds[i]) = hi;
+        *reinterpret_cast<su2*>(As + alds[i] + 32) = mid;
+        *reinterpret_cast<su2*>(As + alds[i] + 64) = lo;
+      }
+    }
+  };
+  auto load_b = [&](int s) {
+    const unsigned so = (unsigned)(s < nsteps ? s : nsteps - 1) * 96u;
+#pragma unroll
+    for (int i = 0; i < BLD; ++i) breg[i] = conv_buf_load_u4(brsrc, boff[i], so);
+  };
+  auto store_b = [&](int stage) {
+    unsigned char* Bs = Bsm + stage * B_STAGE;
+#pragma unroll
+    for (int i = 0; i < BLD; ++i)
+      if (NT * (i + 1) <= BU || blds[i] >= 0) *reinterpret_cast<su4*>(Bs + blds[i]) = breg[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wy = wm * TM;
+  const int a_base = (wy * HC + l31) * ROWB + half * 16;               // + (mt+dy)*HC*ROWB + dx*ROWB + plane*32
+  const int b_base = (wn * WTN + l31) * ROWB + half * 16;              // + nt*32*ROWB + plane*32
+  int a_cur = a_base;
+
+  auto compute = [&](auto tap_c) {
+    constexpr int TAP = decltype(tap_c)::value;
+    constexpr int DY = TAP / 3, DX = TAP % 3;
+    const unsigned char* Bs = Bsm + (TAP % 3) * B_STAGE;
+    sbf8 a[3][TM], b[3][TN];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+        a[pl][mt] = __builtin_bit_cast(sbf8, *reinterpret_cast<const su4*>(smem_b + a_cur + ((mt + DY) * HC + DX) * ROWB + pl * 32));
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt)
+        b[pl][nt] = __builtin_bit_cast(sbf8, *reinterpret_cast<const su4*>(Bs + b_base + nt * 32 * ROWB + pl * 32));
+    }
+    // smallest partial products first
+    constexpr int PA[6] = {1, 0, 2, 0, 1, 0};
+    constexpr int PB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int k = 6 - NPROD; k < 6; ++k)
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[k]][mt], b[PB[k]][nt], acc[mt][nt], 0, 0, 0);
+  };
+
+  setup_seg();
+  load_a();
+  load_b(0);
+  store_a(0);
+  store_b(0);
+  load_b(1);
+  store_b(1);
+  next_chunk(1);
+  __syncthreads();
+  int a_stage = 0;
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int s0 = kc * 9;
+    auto step = [&](auto tap_c) {
+      constexpr int TAP = decltype(tap_c)::value;
+      load_b(s0 + TAP + 2);
+      if constexpr (TAP == 0) load_a();
+      __builtin_amdgcn_sched_barrier(0);
+      compute(tap_c);
+      __builtin_amdgcn_sched_barrier(0);
+      store_b((TAP + 2) % 3);
+      if constexpr (TAP == 8) store_a(a_stage ^ 1);
+      __syncthreads();
+    };
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});
+    step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});
+    step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});
+    next_chunk(kc + 2);
+    a_stage ^= 1;
+    a_cur = a_base + a_stage * A_STAGE;
+  }
+
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int n = n0 + wn * WTN + nt * 32 + l31;
+    const float bv = p.bias[n];
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) {
+      const int y = y0 + wy + mt;
+      if (y >= p.H) continue;
+      const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int x = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (x < p.W) {
+          float v = acc[mt][nt][r] + bv;
+          if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+          p.out[(rowbase + x) * p.ostride + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int TH, int BN, int WGM, int WGN, int NPROD, int FLAGS>
+hipError_t conv_halo_split_launch(const ConvParams& p, hipStream_t s) {
+  constexpr size_t lds = 2 * (size_t)(TH + 2) * 34 * 112 + 3 * (size_t)BN * 112;
+  auto kern = conv_halo_split_kernel<TH, BN, WGM, WGN, NPROD, FLAGS>;
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+  }
+  const int ntx = (p.W + 31) / 32, nty = (p.H + TH - 1) / TH;
+  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, p);
+  return hipGetLastError();
+}

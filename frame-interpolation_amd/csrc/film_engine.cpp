@@ -66,6 +66,8 @@ struct OpDesc {
   int64_t w_off = 0, b_off = 0;
   int64_t w2_off = 0, b2_off = 0;     // flow_head: second 1x1 conv
   int64_t wh_off = -1;                // conv: the layer's conv_halo_kernel weight copy (-1: none)
+  int64_t ws_off = -1;                // conv: the layer's bf16x6 weight copy
+  int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
   int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
@@ -86,6 +88,8 @@ struct LayerPack {
   bool kmajor() const { return !c3 && cout % 32 == 0; }
   int64_t w_off = 0, b_off = 0;
   int64_t wh_off = -1;       // 3x3 K-major layers: second copy packed for conv_halo_kernel, [Cout][ctot/16][9][16]
+  int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
+                             //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
   int ctot() const { return (int)perm.size(); }
   int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
@@ -135,6 +139,7 @@ struct film_handle {
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
 };
@@ -280,7 +285,11 @@ void build_layers(film_t* h) {
     L.b_off = off;
     off += L.cout;
     off = (off + 3) & ~int64_t(3);
-    if (L.has_halo()) { L.wh_off = off; off += L.packed_rows() * L.cout; }
+    if (L.has_halo()) {
+      L.wh_off = off; off += L.packed_rows() * L.cout;
+      off = (off + 3) & ~int64_t(3);
+      L.ws_off = off; off += (L.packed_rows() * L.cout * 3 + 1) / 2;
+    }
     off = (off + 3) & ~int64_t(3);
   }
   h->packed_floats = off;
@@ -353,7 +362,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off;
     op.out = out; op.NB = NB; op.H = H; op.W = W;
     const int64_t M = (int64_t)NB * H * W;
     // Kernel family by layer shape only (never by timing, and not by the batch size): the two kernels sum K in a
@@ -365,7 +374,11 @@ struct Planner {
     const int64_t px = (int64_t)H * W;
     op.halo = L.has_halo() && !any_up && px >= 8192 &&
               (ctot >= 768 || (ctot >= 512 && px >= 100000) || L.cout == 32);
-    op.tile = op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
+    // precision mode bf16x6: every 3x3 conv that is large enough to be matrix-pipe bound
+    op.split = h->opt_precision == 1 && L.has_halo() && !any_up && px >= 2048;
+    if (op.split) op.halo = 0;
+    op.tile = op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
+              : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
     P->ops.push_back(op);
@@ -593,7 +606,9 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].C = op.seg[i].v.C;
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
-      p.ksize = op.ksize; p.w = wts + ((op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off); p.bias = wts + op.b_off;
+      p.ksize = op.ksize;
+      p.w = wts + ((op.tile & CONV_TILE_SPLIT) ? op.ws_off : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
+      p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
       p.M = op.NB * op.H * op.W;
@@ -658,6 +673,12 @@ std::vector<int> halo_candidates(int Cout) {
   return out;
 }
 
+std::vector<int> split_candidates(int Cout) {
+  std::vector<int> out;
+  for (int t : halo_candidates(Cout)) out.push_back((t & ~CONV_TILE_HALO) | CONV_TILE_SPLIT);
+  return out;
+}
+
 std::vector<int> tile_candidates(int Cout) {
   std::vector<int> shapes;
   if (Cout % 128 == 0) shapes = {TILE_128x128, TILE_256x128, TILE_256x64, TILE_128x64, TILE_64x64};
@@ -670,7 +691,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -696,7 +717,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = op.split ? split_candidates(op.Cout) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -810,7 +831,7 @@ std::string plan_json(film_t* h, const Plan& P) {
   for (size_t i = 0; i < h->layers.size(); ++i) {
     const LayerPack& L = h->layers[i];
     o << (i ? "," : "") << "{\"name\":\"" << L.name << "\",\"kh\":" << L.kh << ",\"kw\":" << L.kw << ",\"cin\":" << L.cin
-      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << "}";
+      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << ",\"ws_off\":" << L.ws_off << "}";
   }
   o << "],\"ops\":[";
   for (size_t i = 0; i < P.ops.size(); ++i) {
@@ -818,7 +839,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
       << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
     json_view(o, "in", op.in, P); o << ",";
@@ -1013,6 +1034,31 @@ int film_finalize(film_t* h) {
           for (int co = 0; co < L.cout; ++co) col[(size_t)co * nkc * 144] = row[co];
         }
     }
+    if (L.ws_off >= 0) {  // exact 3-way bf16 split (truncation: 8 + 8 + 8 significant bits), [Cout][chunk][tap][plane][16]
+      uint16_t* ds = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.ws_off);
+      const size_t nkc = (size_t)ct / 16;
+      for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < ct; ++ci) {
+          const int ref = L.perm[ci];
+          if (ref < 0) continue;  // stays zero
+          const float* row = src + ((size_t)tap * L.cin + ref) * L.cout;
+          for (int co = 0; co < L.cout; ++co) {
+            uint32_t xb, hb, rb, mb, qb;
+            const float x = row[co];
+            memcpy(&xb, &x, 4);
+            hb = xb & 0xFFFF0000u;
+            float hf; memcpy(&hf, &hb, 4);
+            const float r = x - hf;
+            memcpy(&rb, &r, 4);
+            mb = rb & 0xFFFF0000u;
+            float mf; memcpy(&mf, &mb, 4);
+            const float q = r - mf;
+            memcpy(&qb, &q, 4);
+            uint16_t* d = ds + ((((size_t)co * nkc + ci / 16) * 9 + tap) * 3) * 16 + ci % 16;
+            d[0] = (uint16_t)(hb >> 16); d[16] = (uint16_t)(mb >> 16); d[32] = (uint16_t)(qb >> 16);
+          }
+        }
+    }
     memcpy(h->packed_host.data() + L.b_off, bw->second.data.data(), sizeof(float) * L.cout);
   }
   int rc = upload_packed(h);
@@ -1061,6 +1107,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "precision")) {
+    if (value != 0 && value != 1) return fail(h, FILM_ERR_INVALID, "precision: 0 (f32) or 1 (bf16x6)");
+    if ((int)value != h->opt_precision) {  // plans carry the kernel choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_precision = (int)value;
+    }
+  }
   else return fail(h, FILM_ERR_NOTFOUND, "unknown option '%s'", key);
   return FILM_OK;
 }

@@ -122,6 +122,11 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "graph"   0/1  replay the plan as a hipGraph (default 1)
  *   "profile" 0/1  record a hipEvent pair around every kernel of the next forwards
  *                  (forces graph off); read the result with film_profile_json
+ *   "precision" p  0 (default): every convolution on the exact fp32 MFMA.  1: "bf16x6" - the large 3x3
+ *                  convolutions split each fp32 operand exactly into three bf16 pieces and accumulate the six
+ *                  partial products >= 2^-16 in fp32 on the bf16 matrix pipe (dropped terms < 2^-23 relative);
+ *                  about 1.5x faster, results differ from mode 0 at the level of a changed summation order.
+ *                  Changing it drops the cached plans.
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in
  *                  4 GiB-per-activation-buffer limit); frame pairs are independent, results do not change */
 int film_set_option(film_t* h, const char* key, int64_t value);

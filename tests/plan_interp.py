@@ -68,8 +68,15 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 wh = packed[op['wh_off']:op['wh_off'] + 9 * ct * co].reshape(co, ct // 16, 3, 3, 16)
                 wh = wh.transpose(2, 3, 1, 4, 0).reshape(3, 3, ct, co)
                 assert np.array_equal(wh, wt), 'halo weight copy differs'
-                if op.get('halo'):
+                if op.get('halo') or op.get('split'):
                     assert ks == 3 and not any(sg['up'] for sg in op['segs'])
+            if op.get('ws_off', -1) >= 0:
+                # bf16x6 copy: three bf16 planes [Cout][chunk][tap][plane][16] that add up to the weight EXACTLY
+                n16 = 9 * ct * co * 3
+                raw = packed[op['ws_off']:op['ws_off'] + (n16 + 1) // 2].view(np.uint16)[:n16]
+                planes = (raw.astype(np.uint32) << 16).view(np.float32).reshape(co, ct // 16, 3, 3, 3, 16)
+                ws = planes.astype(np.float64).sum(axis=4).transpose(2, 3, 1, 4, 0).reshape(3, 3, ct, co)
+                assert np.array_equal(ws.astype(np.float32), wt) and np.array_equal(ws, wt.astype(np.float64)), 'bf16x6 split is not exact'
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             _view(arena, op['out'], nb, h, w)[...] = y

@@ -233,6 +233,30 @@ def test_aux_outputs_match_oracle(published):
             assert a.shape == b.shape and np.abs(a - b).max() < FLOW_TOL, name
 
 
+def test_precision_bf16x6_mode(published):
+    """Opt-in precision mode 1 (exact 3-way bf16 split, six partial products, fp32 accumulate) on the large 3x3
+    convolutions: same north_star bound vs the oracle, and within a changed-summation-order distance of mode 0."""
+    from film_hip.engine import FilmEngine
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    x0, x1 = _pair(1, 128, 192, seed=43)
+    ref = eng.forward(x0, x1)
+    want = fo.film_forward(x0, x1, w, fo.Options())
+    e2 = FilmEngine(opt, device=0)
+    e2.set_weights(w)
+    e2.set_option('precision', 1)
+    plan = e2.plan(1, 128, 192)
+    assert sum(op.get('split', 0) for op in plan['ops']) >= 10          # the mode is really in use at this size
+    got = e2.forward(x0, x1)
+    err_oracle, err_f32 = np.abs(got - want).max(), np.abs(got - ref).max()
+    print(f'bf16x6 vs oracle {err_oracle:.2e}, vs f32 engine {err_f32:.2e}; f32 engine vs oracle {np.abs(ref - want).max():.2e}')
+    assert err_oracle < IMAGE_TOL and err_f32 < 1e-4
+    assert np.array_equal(got, e2.forward(x0, x1))                       # deterministic
+    e2.set_option('precision', 0)                                        # drops the plans, back to the fp32 kernels
+    assert np.array_equal(e2.forward(x0, x1), ref)
+    e2.close()
+
+
 def test_errors(published):
     from film_hip.engine import FilmError
     opt, w, eng = published

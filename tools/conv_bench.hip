@@ -15,6 +15,7 @@
 
 #include "../frame-interpolation_amd/csrc/conv_igemm_impl.h"
 #include "experiments/conv_dma_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_split_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_halo_impl.h"
 
@@ -54,8 +55,11 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 
 #define B(BM, BN, WM, WN, FL) {"buf " #BM "x" #BN " w" #WM "x" #WN " f" #FL, BM, BN, 16, 1, conv_buf_launch<BM, BN, WM, WN, FL>}
 #define H(TH, BN, WM, WN, FL) {"halo " #TH "x32x" #BN " w" #WM "x" #WN " f" #FL, TH * 32, BN, 16, 2, conv_halo_launch<TH, BN, WM, WN, FL>}
+#define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
-    V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4), H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
+    V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4),
+    S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
+    H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
     H(4, 128, 2, 2, 4), H(8, 64, 2, 2, 4), B(256, 64, 4, 1, 4), B(128, 64, 2, 2, 4), B(64, 64, 2, 2, 4),
     B(256, 128, 4, 2, 4), B(256, 32, 4, 1, 4), B(128, 32, 4, 1, 4),
     D(128, 128, 2, 2, 4), D(128, 128, 2, 2, 0),
@@ -76,6 +80,21 @@ __global__ void pack_halo_kernel(const float* src, float* dst, int C, int N) {
   const int k = (int)(i / N), n = (int)(i % N);
   const int tap = k / C, c = k % C;
   dst[(((size_t)n * (C / 16) + c / 16) * 9 + tap) * 16 + c % 16] = src[i];
+}
+
+// [tap*C + c][N] fp32 -> [N][chunk][tap][plane][16] bf16, exact 3-way truncation split
+__global__ void pack_split_kernel(const float* src, unsigned short* dst, int C, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)9 * C * N) return;
+  const int k = (int)(i / N), n = (int)(i % N);
+  const int tap = k / C, c = k % C;
+  const float x = src[i];
+  const unsigned hb = __float_as_uint(x) & 0xFFFF0000u;
+  const float r = x - __uint_as_float(hb);
+  const unsigned mb = __float_as_uint(r) & 0xFFFF0000u;
+  const float q = r - __uint_as_float(mb);
+  unsigned short* d = dst + ((((size_t)n * (C / 16) + c / 16) * 9 + tap) * 3) * 16 + c % 16;
+  d[0] = (unsigned short)(hb >> 16); d[16] = (unsigned short)(mb >> 16); d[32] = (unsigned short)(__float_as_uint(q) >> 16);
 }
 
 __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
@@ -120,10 +139,12 @@ int main(int argc, char** argv) {
     const size_t M = (size_t)sh.NB * sh.H * sh.W;
     const size_t n_in = M * sh.C, n_w = (size_t)sh.ks * sh.ks * sh.C * sh.Cout, n_out = M * sh.Cout;
     float *d_in, *d_w, *d_wt, *d_wh, *d_b, *d_out, *d_zero, *d_ref, *d_md;
+    unsigned short* d_ws;
     CK(hipMalloc(&d_in, n_in * 4));
     CK(hipMalloc(&d_w, n_w * 4));
     CK(hipMalloc(&d_wt, n_w * 4));
     CK(hipMalloc(&d_wh, n_w * 4));
+    CK(hipMalloc(&d_ws, n_w * 6));
     CK(hipMalloc(&d_ref, n_out * 4));
     CK(hipMalloc(&d_md, 4));
     CK(hipMalloc(&d_zero, 256));
@@ -134,6 +155,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_w, n_w, 2u, 0.05f);
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, st, d_b, (size_t)sh.Cout, 3u, 0.1f);
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wt, sh.ks * sh.ks * sh.C, sh.Cout);
+    if (sh.ks == 3) hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_ws, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wh, sh.C, sh.Cout);
     CK(hipStreamSynchronize(st));
     ConvParams p{};
@@ -148,8 +170,8 @@ int main(int argc, char** argv) {
       if (sh.Cout % v.bn || sh.C % v.bkc) continue;
       if (only_variant && !strstr(v.name, only_variant)) continue;
       CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
-      if (v.wkind == 2 && sh.ks != 3) continue;
-      p.w = v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
+      if (v.wkind >= 2 && sh.ks != 3) continue;
+      p.w = v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
       CK(v.fn(p, st));  // warm + correctness
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
       hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
@@ -181,7 +203,7 @@ int main(int argc, char** argv) {
              flops / best * 1e-9, rel < 1e-5 ? "ok" : "(ablation)", rel, maxdiff);
       fflush(stdout);
     }
-    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
+    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   return 0;
 }
