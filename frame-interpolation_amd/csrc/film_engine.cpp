@@ -68,6 +68,9 @@ struct OpDesc {
   int64_t wh_off = -1;                // conv: the layer's conv_halo_kernel weight copy (-1: none)
   int64_t ws_off = -1;                // conv: the layer's bf16x6 weight copy
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
+  int lane = 0;                       // graph replay: 0 = main stream, 1 = side stream (small / HBM-bound work)
+  std::vector<int> xdeps;             // ops on the OTHER lane this op must wait for (from the buffer overlap analysis)
+  bool signal = false;                // some op on the other lane waits for this one
   int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
@@ -109,6 +112,7 @@ struct Plan {
   hipGraphExec_t graph_exec = nullptr;
   hipGraph_t graph = nullptr;
   std::vector<hipEvent_t> ev;
+  std::vector<hipEvent_t> lane_ev;    // one per signalling op (index = op index), lazily created; + fork/join at the end
   uint64_t last_use = 0;
   int find(const std::string& n) const {
     for (size_t i = 0; i < bufs.size(); ++i)
@@ -139,6 +143,8 @@ struct film_handle {
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_lanes = 1;      // 1: replay graphs use a second (side) stream for independent small / HBM-bound work
+  hipStream_t stream2 = nullptr;
   int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
@@ -431,8 +437,20 @@ struct Planner {
         if (j + 1 < std::min(L - i, c.sub_levels))
           fxp_sz = std::max<int64_t>(fxp_sz, (int64_t)N2 * HL(i + j + 1) * WL(i + j + 1) * (c.filters << j));
       }
-    const int fx_a = add_scratch("scratch_fx_a", fx_sz);
-    const int fx_p = add_scratch("scratch_fx_p", fxp_sz);
+    // one scratch pair per pyramid level's subtree: the subtrees are independent chains (two of them run beside the
+    // rest on the side stream of the replay graph) and 288 GB of HBM makes sharing pointless
+    std::vector<int> fx_a_v(L), fx_p_v(L);
+    for (int i = 0; i < L; ++i) {
+      int64_t a_sz = 0, p_sz = 0;
+      for (int j = 0; j < std::min(L - i, c.sub_levels); ++j) {
+        a_sz = std::max<int64_t>(a_sz, (int64_t)N2 * HL(i + j) * WL(i + j) * (c.filters << j));
+        if (j + 1 < std::min(L - i, c.sub_levels))
+          p_sz = std::max<int64_t>(p_sz, (int64_t)N2 * HL(i + j + 1) * WL(i + j + 1) * (c.filters << j));
+      }
+      fx_a_v[i] = add_scratch("scratch_fx_a" + std::to_string(i), a_sz);
+      fx_p_v[i] = add_scratch("scratch_fx_p" + std::to_string(i), p_sz);
+    }
+    (void)fx_sz; (void)fxp_sz;
     for (int l = 0; l < L; ++l) {
       const int nf = c.flow_filters[predictor_index(c, l)];
       fp_sz = std::max<int64_t>(fp_sz, (int64_t)N2 * HL(l) * WL(l) * nf);
@@ -462,6 +480,8 @@ struct Planner {
     // ---- cascaded feature extractor (feature_extractor.py:163-193) --------------------------------
     for (int i = 0; i < L; ++i) {
       const int n = std::min(L - i, c.sub_levels);
+      const int fx_a = fx_a_v[i], fx_p = fx_p_v[i];
+      const size_t first_op = P->ops.size();
       for (int j = 0; j < n; ++j) {
         const int lv = i + j, k = c.filters << j;
         const std::string tg = "feat_s" + std::to_string(i) + "_" + std::to_string(j);
@@ -488,11 +508,15 @@ struct Planner {
         conv(tg, w1, {s1}, dst, N2, HL(lv), WL(lv), true);
         if (j < n - 1) pool(tg + ":pool", dst, scratch(fx_p, k), N2, HL(lv), WL(lv));
       }
+      // every subtree but the level-0 one (75 % of the extractor's FLOPs) goes to the side stream: they and the coarse
+      // flow levels that need only them are small, latency-bound launches that hide under the level-0 subtree
+      if (i >= 1) for (size_t q = first_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
     }
 
     // ---- bidirectional coarse-to-fine flow (pyramid_flow_estimator.py:125-163) ---------------------
     // batch n = d*B + b: d = 0 forward (a = image 0, b = image 1), d = 1 backward.
     for (int l = L - 1; l >= 0; --l) {
+      const size_t first_flow_op = P->ops.size();
       const std::string tg = "flow_l" + std::to_string(l);
       const int pi = predictor_index(c, l);
       const int nf = c.flow_filters[pi], nconv = c.flow_convs[pi];
@@ -546,12 +570,18 @@ struct Planner {
         ad.n = (int64_t)N2 * Hl * Wl * 2; ad.bytes = 4.0 * ad.n * 3;
         P->ops.push_back(ad);
       }
+      // levels >= 4 read features of subtrees >= 1 only (level 3 needs the last stage of the level-0 subtree)
+      if (l >= 4) for (size_t q = first_flow_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
     }
 
     // ---- warp to t = 0.5 and build the aligned pyramid (interpolator.py:153-183) ------------------
     // util.flow_pyramid_synthesis recomputes exactly the v sequence above, so v is reused.
     // image s is sampled with the flow of the opposite direction: image 0 <- backward flow (d=1).
-    for (int l = 0; l < FL; ++l) {
+    // Emitted coarse to fine and on the side stream: level l only needs v[l], which the flow estimator finishes
+    // early for the coarse levels; the level-0 warps (60 % of the warp bytes, HBM bound) then overlap the
+    // coarse fusion convolutions (matrix-pipe bound) of the main stream.
+    const size_t first_align_op = P->ops.size();
+    for (int l = FL - 1; l >= 0; --l) {
       const std::string tg = "align_l" + std::to_string(l);
       for (int s = 0; s < 2; ++s) {
         View fl = view(v[l], (1 - s) * B, 0, 2);
@@ -568,6 +598,7 @@ struct Planner {
       pk.n = (int64_t)B * HL(l) * WL(l); pk.bytes = 4.0 * pk.n * 14;
       P->ops.push_back(pk);
     }
+    for (size_t q = first_align_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
 
     // ---- fusion decoder (fusion.py:103-140) ---------------------------------------------------------
     View net = view(aligned[FL - 1], 0, 0, 2 * fc[FL - 1] + 16);
@@ -585,7 +616,46 @@ struct Planner {
     }
     conv_pw("fusion_out", "fusion/output_conv", net, view(out, 0, 0, 3), (int64_t)B * H * W, false);
     if (bad) return fail(h, FILM_ERR_INVALID, "%s", bad_msg.c_str());
+    analyze_lanes();
     return FILM_OK;
+  }
+
+  // ---- cross-lane dependencies from buffer overlap -------------------------------------------------------------
+  struct Access { int buf; int c0, c1; };  // channels [c0, c1) of every pixel of a buffer (scratch: everything)
+  Access access(const View& v) const {
+    const Buffer& b = P->bufs[v.buf];
+    if (b.C == 0 || v.stride != b.C) return {v.buf, 0, 1 << 30};  // scratch, or a reinterpreted view: whole buffer
+    const int c0 = (int)((v.off - b.off) % b.C);
+    return {v.buf, c0, c0 + v.C};
+  }
+  static bool overlap(const Access& a, const Access& b) { return a.buf == b.buf && a.c0 < b.c1 && b.c0 < a.c1; }
+  void accesses(const OpDesc& op, std::vector<Access>& rd, std::vector<Access>& wr) const {
+    rd.clear(); wr.clear();
+    if (op.kind == OP_CONV) for (int i = 0; i < op.nseg; ++i) rd.push_back(access(op.seg[i].v));
+    else { if (op.in.buf >= 0) rd.push_back(access(op.in)); if (op.in2.buf >= 0) rd.push_back(access(op.in2)); }
+    if (op.out.buf >= 0) wr.push_back(access(op.out));
+  }
+  // For every op: the LAST op of the other lane it conflicts with (RAW, WAR or WAW on overlapping channels of a
+  // buffer).  Waiting for the last one is enough: a lane executes in program order.
+  void analyze_lanes() {
+    const size_t n = P->ops.size();
+    std::vector<std::vector<Access>> rd(n), wr(n);
+    for (size_t i = 0; i < n; ++i) accesses(P->ops[i], rd[i], wr[i]);
+    for (size_t j = 0; j < n; ++j) {
+      OpDesc& oj = P->ops[j];
+      for (size_t ii = j; ii-- > 0;) {
+        const OpDesc& oi = P->ops[ii];
+        if (oi.lane == oj.lane) continue;
+        bool hit = false;
+        for (const Access& w : wr[ii]) {
+          for (const Access& r : rd[j]) hit |= overlap(w, r);
+          for (const Access& w2 : wr[j]) hit |= overlap(w, w2);
+        }
+        for (const Access& r : rd[ii])
+          for (const Access& w2 : wr[j]) hit |= overlap(r, w2);
+        if (hit) { oj.xdeps.push_back((int)ii); P->ops[ii].signal = true; break; }
+      }
+    }
   }
 };
 
@@ -758,6 +828,7 @@ void free_plan(Plan* p) {
   if (p->graph_exec) (void)hipGraphExecDestroy(p->graph_exec);
   if (p->graph) (void)hipGraphDestroy(p->graph);
   for (auto e : p->ev) (void)hipEventDestroy(e);
+  for (auto e : p->lane_ev) if (e) (void)hipEventDestroy(e);
   if (p->arena) (void)hipFree(p->arena);
 }
 
@@ -839,7 +910,8 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"lane\":" << op.lane << ",\"xdeps\":["
+      << [&] { std::string d; for (size_t q = 0; q < op.xdeps.size(); ++q) d += (q ? "," : "") + std::to_string(op.xdeps[q]); return d; }() << "]" << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
       << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
     json_view(o, "in", op.in, P); o << ",";
@@ -936,7 +1008,8 @@ int film_create(film_t** out, int device, const film_config* cfg) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && strncmp(prop.gcnArchName, "gfx950", 6) != 0)
       return fail(nullptr, FILM_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess)
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking) != hipSuccess)
       return fail(nullptr, FILM_ERR_HIP, "hipStreamCreate failed");
   }
   build_layers(h.get());
@@ -954,6 +1027,7 @@ void film_destroy(film_t* h) {
   if (h->packed_dev) (void)hipFree(h->packed_dev);
   if (h->stage) (void)hipFree(h->stage);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream2) (void)hipStreamDestroy(h->stream2);
   delete h;
 }
 
@@ -1107,6 +1181,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "lanes")) {
+    if ((value != 0) != (h->opt_lanes != 0)) {  // captured graphs carry the lane structure: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) {
+        if (p->graph_exec) { (void)hipGraphExecDestroy(p->graph_exec); p->graph_exec = nullptr; }
+        if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+      }
+      h->opt_lanes = value != 0;
+    }
+  }
   else if (!strcmp(key, "precision")) {
     if (value != 0 && value != 1) return fail(h, FILM_ERR_INVALID, "precision: 0 (f32) or 1 (bf16x6)");
     if ((int)value != h->opt_precision) {  // plans carry the kernel choice: drop them
@@ -1281,9 +1365,33 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
     if (!P->graph_exec) {
       // capture on the handle's own stream, replay on whichever stream the caller wants
       HIPCHK(h, hipStreamSynchronize(s));
+      // two capture streams: lane 1 (small subtrees, coarse flow levels, the t = 0.5 warps) forks from and joins
+      // the main stream; cross-lane ordering = the events found by Planner::analyze_lanes
+      const size_t nops = P->ops.size();
+      if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
+      auto event_of = [&](size_t i) -> hipEvent_t {
+        if (!P->lane_ev[i]) (void)hipEventCreateWithFlags(&P->lane_ev[i], hipEventDisableTiming);
+        return P->lane_ev[i];
+      };
+      const bool two_lanes = h->opt_lanes != 0;
       HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
       hipError_t le = hipSuccess;
-      for (const OpDesc& op : P->ops) { le = launch_op(op, P->arena, h->packed_dev, h->stream); if (le != hipSuccess) break; }
+      if (two_lanes) {
+        le = hipEventRecord(event_of(nops), h->stream);
+        if (le == hipSuccess) le = hipStreamWaitEvent(h->stream2, event_of(nops), 0);
+      }
+      for (size_t i = 0; i < nops && le == hipSuccess; ++i) {
+        const OpDesc& op = P->ops[i];
+        hipStream_t ls = (two_lanes && op.lane == 1) ? h->stream2 : h->stream;
+        if (two_lanes)
+          for (int d : op.xdeps) { le = hipStreamWaitEvent(ls, event_of((size_t)d), 0); if (le != hipSuccess) break; }
+        if (le == hipSuccess) le = launch_op(op, P->arena, h->packed_dev, ls);
+        if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
+      }
+      if (two_lanes && le == hipSuccess) {
+        le = hipEventRecord(event_of(nops + 1), h->stream2);
+        if (le == hipSuccess) le = hipStreamWaitEvent(h->stream, event_of(nops + 1), 0);
+      }
       hipError_t ce = hipStreamEndCapture(h->stream, &P->graph);
       if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed during capture: %s", hipGetErrorString(le));
       HIPCHK(h, ce);

@@ -127,6 +127,9 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  partial products >= 2^-16 in fp32 on the bf16 matrix pipe (dropped terms < 2^-23 relative);
  *                  about 1.5x faster, results differ from mode 0 at the level of a changed summation order.
  *                  Changing it drops the cached plans.
+ *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
+ *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
+ *                  (default 1); ordering between the two comes from a buffer-overlap analysis of the plan
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in
  *                  4 GiB-per-activation-buffer limit); frame pairs are independent, results do not change */
 int film_set_option(film_t* h, const char* key, int64_t value);

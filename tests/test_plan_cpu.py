@@ -181,3 +181,57 @@ def test_invalid_options_rejected():
         Options(pyramid_levels=3, fusion_pyramid_levels=5).validate()   # interpolator.py:120-122
     with pytest.raises(ValueError):
         Options(filters=20).validate()
+
+
+def test_lane_analysis_orders_every_conflict(tiny_weights):
+    """Two-stream replay: for every pair of ops on different lanes that touch overlapping channels of one buffer
+    (RAW / WAR / WAW) the later one must be ordered behind the earlier one through the xdeps edges + per-lane
+    program order (happens-before closure computed here independently from the plan JSON)."""
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED, TINY
+    for opt, shape in ((TINY, (2, 64, 96)), (PUBLISHED, (1, 128, 192))):
+        eng = FilmEngine(opt, device=-1)
+        plan = eng.plan(*shape)
+        bufs = {b['name']: b for b in plan['buffers']}
+        ops = plan['ops']
+
+        def acc(v):
+            if v is None or not v.get('buf'):
+                return None
+            b = bufs[v['buf']]
+            if b['C'] == 0 or v['stride'] != b['C']:
+                return (v['buf'], 0, 1 << 30)
+            c0 = (v['off'] - b['off']) % b['C']
+            return (v['buf'], c0, c0 + v['C'])
+
+        def rw(op):
+            rd = [acc(sg['v']) for sg in op.get('segs', [])] if op['kind'] == 'conv_mfma' else [acc(op.get('in')), acc(op.get('in2'))]
+            return [a for a in rd if a], [a for a in [acc(op.get('out'))] if a]
+
+        def hit(a, b):
+            return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
+
+        n = len(ops)
+        assert {o['lane'] for o in ops} == {0, 1}
+        # done[j] = set of ops guaranteed complete before op j starts
+        before = [set() for _ in range(n)]
+        last = {0: None, 1: None}
+        for j, o in enumerate(ops):
+            preds = list(o['xdeps'])
+            if last[o['lane']] is not None:
+                preds.append(last[o['lane']])
+            for p in preds:
+                assert p < j
+                before[j] |= before[p] | {p}
+            last[o['lane']] = j
+        acc_rw = [rw(o) for o in ops]
+        for j in range(n):
+            rj, wj = acc_rw[j]
+            for i in range(j):
+                if ops[i]['lane'] == ops[j]['lane']:
+                    continue
+                ri, wi = acc_rw[i]
+                conflict = any(hit(w, r) for w in wi for r in rj) or any(hit(w, w2) for w in wi for w2 in wj) or \
+                    any(hit(r, w2) for r in ri for w2 in wj)
+                if conflict:
+                    assert i in before[j], (ops[i]['tag'], ops[j]['tag'])
