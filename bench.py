@@ -140,6 +140,8 @@ def main():
         # one-time RCCL broadcast of the packed weight blob (137.7 MB) from rank 0
         from film_hip.sharding import broadcast_weights
         broadcast_weights(eng, dist, src=0, device=dev)
+    if os.environ.get('FILM_TUNE_MS'):
+        eng.set_option('tune_ms', int(os.environ['FILM_TUNE_MS']))
     if args.no_graph:
         eng.set_option('graph', 0)
     if args.precision:

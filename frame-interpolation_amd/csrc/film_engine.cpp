@@ -143,6 +143,8 @@ struct film_handle {
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
+  int opt_tune_ms = 0;    // autotune: minimum kernel time spent per candidate (0: two launches)
   int opt_lanes = 1;      // 1: replay graphs use a second (side) stream for independent small / HBM-bound work
   hipStream_t stream2 = nullptr;
   int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs
@@ -378,10 +380,13 @@ struct Planner {
     bool any_up = false;
     for (int i = 0; i < op.nseg; ++i) any_up |= segs[i].up != 0;
     const int64_t px = (int64_t)H * W;
-    op.halo = L.has_halo() && !any_up && px >= 8192 &&
-              (ctot >= 768 || (ctot >= 512 && px >= 100000) || L.cout == 32);
+    if (h->opt_halo_all)  // tuning / test knob: every eligible 3x3 conv, whatever its size
+      op.halo = L.has_halo() && !any_up;
+    else
+      op.halo = L.has_halo() && !any_up && px >= 8192 &&
+                (ctot >= 768 || (ctot >= 512 && px >= 100000) || L.cout == 32);
     // precision mode bf16x6: every 3x3 conv that is large enough to be matrix-pipe bound
-    op.split = h->opt_precision == 1 && L.has_halo() && !any_up && px >= 2048;
+    op.split = h->opt_precision == 1 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all);
     if (op.split) op.halo = 0;
     op.tile = op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
@@ -799,8 +804,10 @@ int autotune_plan(film_t* h, Plan* P) {
         OpDesc trial = op;
         trial.tile = tile;
         HIPCHK(h, launch_op(trial, P->arena, h->packed_dev, h->stream));  // warm
-        float ms_min = 1e30f;
-        for (int rep = 0; rep < 2; ++rep) {
+        float ms_min = 1e30f, ms_sum = 0.f;
+        // at least two timed launches; with the "tune_ms" option keep going until that much kernel time has been
+        // spent on the candidate (long enough for the power-limited clock to settle)
+        for (int rep = 0; rep < 2 || (ms_sum < (float)h->opt_tune_ms && rep < 64); ++rep) {
           HIPCHK(h, hipEventRecord(e0, h->stream));
           HIPCHK(h, launch_op(trial, P->arena, h->packed_dev, h->stream));
           HIPCHK(h, hipEventRecord(e1, h->stream));
@@ -808,6 +815,7 @@ int autotune_plan(film_t* h, Plan* P) {
           float ms = 0;
           HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
           ms_min = std::min(ms_min, ms);
+          ms_sum += ms;
         }
         if (ms_min < best_ms) { best_ms = ms_min; best = tile; }
       }
@@ -1181,6 +1189,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "tune_ms")) h->opt_tune_ms = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "halo_all")) {
+    if ((value != 0) != (h->opt_halo_all != 0)) {  // plans carry the kernel choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_halo_all = value != 0;
+    }
+  }
   else if (!strcmp(key, "lanes")) {
     if ((value != 0) != (h->opt_lanes != 0)) {  // captured graphs carry the lane structure: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }

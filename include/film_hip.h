@@ -130,6 +130,9 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
  *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
  *                  (default 1); ordering between the two comes from a buffer-overlap analysis of the plan
+ *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
+ *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
+ *                  Test / tuning knobs; "halo_all" drops the cached plans.
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in
  *                  4 GiB-per-activation-buffer limit); frame pairs are independent, results do not change */
 int film_set_option(film_t* h, const char* key, int64_t value);

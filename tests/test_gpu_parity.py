@@ -257,6 +257,27 @@ def test_precision_bf16x6_mode(published):
     e2.close()
 
 
+@pytest.mark.parametrize('precision', [0, 1])
+@pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192)])
+def test_halo_kernels_on_every_level(published, precision, b, h, w):
+    """halo_all = 1 forces conv_halo_kernel (precision 0) / conv_halo_split_kernel (precision 1) onto every 3x3
+    convolution, i.e. onto ragged patches down to 1 x 1 pixels (W < 32, H not a multiple of the patch height),
+    multi-segment inputs and batch remaps: stage-by-stage parity with the oracle."""
+    from film_hip.engine import FilmEngine
+    opt, wts, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(wts)
+    eng.set_option('halo_all', 1)
+    eng.set_option('precision', precision)
+    plan = eng.plan(b, h, w)
+    key = 'split' if precision else 'halo'
+    n3 = sum(1 for op in plan['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 3 and not op['c3'])
+    assert sum(op[key] for op in plan['ops']) == n3 > 40
+    x0, x1 = _pair(b, h, w, seed=47 + h + w)
+    _check_stages(eng, opt, wts, x0, x1)
+    eng.close()
+
+
 def test_errors(published):
     from film_hip.engine import FilmError
     opt, w, eng = published
