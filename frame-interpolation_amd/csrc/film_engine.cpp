@@ -1088,14 +1088,43 @@ int film_finalize(film_t* h) {
         for (int c = 0; c < 3; ++c)
           memcpy(dst + ((size_t)tap * 4 + c) * L.cout, src + ((size_t)tap * 3 + c) * L.cout, sizeof(float) * L.cout);
     } else if (L.kmajor()) {
-      const size_t ktot = (size_t)L.kh * L.kw * ct;
-      for (int tap = 0; tap < L.kh * L.kw; ++tap)
-        for (int ci = 0; ci < ct; ++ci) {
-          const int ref = L.perm[ci];
-          if (ref < 0) continue;  // zero column (padding channel)
-          const float* row = src + ((size_t)tap * L.cin + ref) * L.cout;
-          float* col = dst + (size_t)tap * ct + ci;
-          for (int co = 0; co < L.cout; ++co) col[co * ktot] = row[co];
+      // One pass per (tap, 16-channel chunk): the 16 source rows (each `cout` contiguous floats) stay in L1 while
+      // every output channel receives its 16 contiguous k values - in the K-major copy, in the halo copy and (3x3
+      // layers) as three bf16 planes.  (A channel-outer loop with one strided store per weight took 17 s here.)
+      const int ntap = L.kh * L.kw;
+      const size_t ktot = (size_t)ntap * ct;
+      const size_t nkc = (size_t)ct / 16;
+      float* dh = L.wh_off >= 0 ? h->packed_host.data() + L.wh_off : nullptr;
+      uint16_t* ds = L.ws_off >= 0 ? reinterpret_cast<uint16_t*>(h->packed_host.data() + L.ws_off) : nullptr;
+      for (int tap = 0; tap < ntap; ++tap)
+        for (size_t kc = 0; kc < nkc; ++kc) {
+          const float* rows[16];
+          for (int j = 0; j < 16; ++j) {
+            const int ref = L.perm[kc * 16 + j];
+            rows[j] = ref < 0 ? nullptr : src + ((size_t)tap * L.cin + ref) * L.cout;  // nullptr: zero (padding) channel
+          }
+          for (int co = 0; co < L.cout; ++co) {
+            float v[16];
+            for (int j = 0; j < 16; ++j) v[j] = rows[j] ? rows[j][co] : 0.f;
+            memcpy(dst + (size_t)co * ktot + (size_t)tap * ct + kc * 16, v, sizeof(v));
+            if (dh) memcpy(dh + (((size_t)co * nkc + kc) * 9 + tap) * 16, v, sizeof(v));
+            if (ds) {  // exact 3-way bf16 split by truncation: 8 + 8 + 8 significant bits
+              uint16_t* d = ds + (((size_t)co * nkc + kc) * 9 + tap) * 48;
+              for (int j = 0; j < 16; ++j) {
+                uint32_t xb, hb, rb, mb, qb;
+                memcpy(&xb, &v[j], 4);
+                hb = xb & 0xFFFF0000u;
+                float hf; memcpy(&hf, &hb, 4);
+                const float r = v[j] - hf;
+                memcpy(&rb, &r, 4);
+                mb = rb & 0xFFFF0000u;
+                float mf; memcpy(&mf, &mb, 4);
+                const float q = r - mf;
+                memcpy(&qb, &q, 4);
+                d[j] = (uint16_t)(hb >> 16); d[16 + j] = (uint16_t)(mb >> 16); d[32 + j] = (uint16_t)(qb >> 16);
+              }
+            }
+          }
         }
     } else
     for (int tap = 0; tap < L.kh * L.kw; ++tap)
@@ -1104,43 +1133,6 @@ int film_finalize(film_t* h) {
         if (ref < 0) continue;  // zero row (padding channel)
         memcpy(dst + ((size_t)tap * ct + ci) * L.cout, src + ((size_t)tap * L.cin + ref) * L.cout, sizeof(float) * L.cout);
       }
-    if (L.wh_off >= 0) {  // [Cout][chunk][tap][16] copy for conv_halo_kernel
-      float* dh = h->packed_host.data() + L.wh_off;
-      const size_t nkc = (size_t)ct / 16;
-      for (int tap = 0; tap < 9; ++tap)
-        for (int ci = 0; ci < ct; ++ci) {
-          const int ref = L.perm[ci];
-          if (ref < 0) continue;
-          const float* row = src + ((size_t)tap * L.cin + ref) * L.cout;
-          float* col = dh + ((size_t)(ci / 16) * 9 + tap) * 16 + ci % 16;
-          for (int co = 0; co < L.cout; ++co) col[(size_t)co * nkc * 144] = row[co];
-        }
-    }
-    if (L.ws_off >= 0) {  // exact 3-way bf16 split (truncation: 8 + 8 + 8 significant bits), [Cout][chunk][tap][plane][16]
-      uint16_t* ds = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.ws_off);
-      const size_t nkc = (size_t)ct / 16;
-      for (int tap = 0; tap < 9; ++tap)
-        for (int ci = 0; ci < ct; ++ci) {
-          const int ref = L.perm[ci];
-          if (ref < 0) continue;  // stays zero
-          const float* row = src + ((size_t)tap * L.cin + ref) * L.cout;
-          for (int co = 0; co < L.cout; ++co) {
-            uint32_t xb, hb, rb, mb, qb;
-            const float x = row[co];
-            memcpy(&xb, &x, 4);
-            hb = xb & 0xFFFF0000u;
-            float hf; memcpy(&hf, &hb, 4);
-            const float r = x - hf;
-            memcpy(&rb, &r, 4);
-            mb = rb & 0xFFFF0000u;
-            float mf; memcpy(&mf, &mb, 4);
-            const float q = r - mf;
-            memcpy(&qb, &q, 4);
-            uint16_t* d = ds + ((((size_t)co * nkc + ci / 16) * 9 + tap) * 3) * 16 + ci % 16;
-            d[0] = (uint16_t)(hb >> 16); d[16] = (uint16_t)(mb >> 16); d[32] = (uint16_t)(qb >> 16);
-          }
-        }
-    }
     memcpy(h->packed_host.data() + L.b_off, bw->second.data.data(), sizeof(float) * L.cout);
   }
   int rc = upload_packed(h);
