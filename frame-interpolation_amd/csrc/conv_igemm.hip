@@ -15,7 +15,9 @@
 //     bank-conflict free (MI355X_MICROARCH.md, LDS table: rows distinct mod 16 per 16-lane group).
 //   * the epilogue adds the bias, applies leaky_relu and stores 128-byte rows into the channel slice
 //     of the destination buffer (the consumer's concat input).
-// Three kernel templates:
+// Kernel templates (the family of a layer is a pure function of its shape and the precision option):
+//   conv_wino_impl.h   3x3 convs with Cout % 128 == 0 on the large levels: 1-D Winograd F(2,3) along x on the halo
+//                      staging, 1.5x fewer fp32 MFMAs.
 //   conv_halo_impl.h   3x3 convs with deep K: the activation halo patch is staged once per 16-channel chunk and the
 //                      nine taps run out of LDS (6.8x fewer A loads / LDS stores, less L2 traffic, higher clocks).
 //   conv_buf_impl.h    the general kernel: buffer loads with hardware zero fill, K-major weights, no vector
@@ -26,6 +28,7 @@
 #include "conv_buf_impl.h"
 #include "conv_halo_impl.h"
 #include "conv_split_impl.h"
+#include "conv_wino_impl.h"
 #include "conv_igemm_impl.h"
 
 template <int F>
@@ -80,10 +83,24 @@ static hipError_t launch_split(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+template <int F>
+static hipError_t launch_wino(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case WINO_4x128: return conv_wino_launch<4, 128, 4, 2, F>(p, s);
+    case WINO_4x64: return conv_wino_launch<4, 64, 4, 1, F>(p, s);
+    case WINO_2x128: return conv_wino_launch<2, 128, 2, 2, F>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
+  if (tile & CONV_TILE_WINO) {
+    if (p.ksize != 3) return hipErrorInvalidValue;
+    return (tile & CONV_TILE_XCD) ? launch_wino<CONV_B_XCD_M>(p, shape, s) : launch_wino<0>(p, shape, s);
+  }
   if (tile & CONV_TILE_SPLIT) {
     if (p.ksize != 3) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_split<CONV_B_XCD_M>(p, shape, s) : launch_split<0>(p, shape, s);

@@ -1,8 +1,7 @@
-// conv_wino_impl.h -- EXPERIMENT (tools/conv_bench.hip only, not part of libfilm_hip.so).  Measured on MI355X: 167-183
-// TFLOP/s (direct-conv FLOPs) on the large-M layers vs 137-143 for the direct kernels (+22-28 %), 144 vs 133 on the
-// deep small-M layers (+8 %): the 1.5x MFMA saving is mostly paid back in LDS traffic, occupancy (128 accumulator
-// registers -> 2 waves per SIMD, one 8-wave workgroup per CU) and clock (2.19 GHz at 79 % pipe occupancy).  Not
-// integrated this round (est. +5-7 % on the whole forward for a fourth weight layout and a changed rounding).
+// conv_wino_impl.h -- Measured on MI355X (tools/conv_bench.hip): 167-183 TFLOP/s (direct-conv FLOPs) on the large-M
+// layers vs 137-143 for the direct kernels (+22-28 %), 144 vs 133 on the deep small-M layers: the 1.5x MFMA saving is
+// partly paid back in LDS traffic, occupancy (128 accumulator registers -> 2 waves per SIMD, one 8-wave workgroup per
+// CU) and clock (2.19 GHz at 79 % pipe occupancy).  Used for 3x3 layers with Cout % 128 == 0 on the large levels.
 //
 // 3x3 Conv2D('same') + bias + leaky_relu with the 1-D Winograd transform F(2,3) along x on top
 // of the halo-staged implicit GEMM: 12 matrix steps per 16-channel chunk instead of 18 for every PAIR of output
@@ -23,7 +22,7 @@
 //     buffered): one barrier per 3 x 16 MFMAs per wave instead of one per 16;
 //   * accumulators: 4 (nu) x TN tiles per output row; the output transform runs on them in the epilogue.
 #pragma once
-#include "../../frame-interpolation_amd/csrc/conv_buf_impl.h"
+#include "conv_buf_impl.h"
 
 template <int TH, int BN, int WGM, int WGN, int FLAGS>
 __global__ __launch_bounds__(WGM* WGN * 64) void conv_wino_kernel(ConvParams p) {

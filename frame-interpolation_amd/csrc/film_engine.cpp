@@ -67,6 +67,8 @@ struct OpDesc {
   int64_t w2_off = 0, b2_off = 0;     // flow_head: second 1x1 conv
   int64_t wh_off = -1;                // conv: the layer's conv_halo_kernel weight copy (-1: none)
   int64_t ws_off = -1;                // conv: the layer's bf16x6 weight copy
+  int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
+  int wino = 0;                       // conv: runs on conv_wino_kernel
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
   int lane = 0;                       // graph replay: 0 = main stream, 1 = side stream (small / HBM-bound work)
   std::vector<int> xdeps;             // ops on the OTHER lane this op must wait for (from the buffer overlap analysis)
@@ -91,6 +93,7 @@ struct LayerPack {
   bool kmajor() const { return !c3 && cout % 32 == 0; }
   int64_t w_off = 0, b_off = 0;
   int64_t wh_off = -1;       // 3x3 K-major layers: second copy packed for conv_halo_kernel, [Cout][ctot/16][9][16]
+  int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/16][12][16]
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
                              //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
@@ -143,6 +146,7 @@ struct film_handle {
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_wino = 1;       // 0: never, 1: Winograd F(2,3) kernel where measured faster (default), 2: every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
   int opt_tune_ms = 0;    // autotune: minimum kernel time spent per candidate (0: two launches)
   int opt_lanes = 1;      // 1: replay graphs use a second (side) stream for independent small / HBM-bound work
@@ -297,6 +301,8 @@ void build_layers(film_t* h) {
       L.wh_off = off; off += L.packed_rows() * L.cout;
       off = (off + 3) & ~int64_t(3);
       L.ws_off = off; off += (L.packed_rows() * L.cout * 3 + 1) / 2;
+      off = (off + 3) & ~int64_t(3);
+      if (L.cout % 64 == 0) { L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12; }
     }
     off = (off + 3) & ~int64_t(3);
   }
@@ -370,7 +376,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off;
     op.out = out; op.NB = NB; op.H = H; op.W = W;
     const int64_t M = (int64_t)NB * H * W;
     // Kernel family by layer shape only (never by timing, and not by the batch size): the two kernels sum K in a
@@ -387,8 +393,12 @@ struct Planner {
                 (ctot >= 768 || (ctot >= 512 && px >= 100000) || L.cout == 32);
     // precision mode bf16x6: every 3x3 conv that is large enough to be matrix-pipe bound
     op.split = h->opt_precision == 1 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all);
-    if (op.split) op.halo = 0;
-    op.tile = op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
+    // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M
+    op.wino = !op.split && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
+              ((L.cout % 128 == 0 && px >= 30000) || h->opt_wino == 2);
+    if (op.split || op.wino) op.halo = 0;
+    op.tile = op.wino ? ((L.cout % 128 == 0 ? WINO_4x128 : WINO_4x64) | CONV_TILE_WINO | CONV_TILE_XCD)
+              : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
@@ -682,7 +692,8 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
       p.ksize = op.ksize;
-      p.w = wts + ((op.tile & CONV_TILE_SPLIT) ? op.ws_off : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
+      p.w = wts + ((op.tile & CONV_TILE_WINO) ? op.ww_off : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
+                   : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
       p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
@@ -748,6 +759,13 @@ std::vector<int> halo_candidates(int Cout) {
   return out;
 }
 
+std::vector<int> wino_candidates(int Cout) {
+  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x128, WINO_4x64, WINO_2x128} : std::vector<int>{WINO_4x64};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> split_candidates(int Cout) {
   std::vector<int> out;
   for (int t : halo_candidates(Cout)) out.push_back((t & ~CONV_TILE_HALO) | CONV_TILE_SPLIT);
@@ -766,7 +784,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -792,7 +810,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = op.split ? split_candidates(op.Cout) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -910,7 +928,7 @@ std::string plan_json(film_t* h, const Plan& P) {
   for (size_t i = 0; i < h->layers.size(); ++i) {
     const LayerPack& L = h->layers[i];
     o << (i ? "," : "") << "{\"name\":\"" << L.name << "\",\"kh\":" << L.kh << ",\"kw\":" << L.kw << ",\"cin\":" << L.cin
-      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << ",\"ws_off\":" << L.ws_off << "}";
+      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << ",\"ws_off\":" << L.ws_off << ",\"ww_off\":" << L.ww_off << "}";
   }
   o << "],\"ops\":[";
   for (size_t i = 0; i < P.ops.size(); ++i) {
@@ -918,7 +936,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"lane\":" << op.lane << ",\"xdeps\":["
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wino\":" << op.wino << ",\"lane\":" << op.lane << ",\"xdeps\":["
       << [&] { std::string d; for (size_t q = 0; q < op.xdeps.size(); ++q) d += (q ? "," : "") + std::to_string(op.xdeps[q]); return d; }() << "]" << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
       << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
@@ -1126,6 +1144,28 @@ int film_finalize(film_t* h) {
             }
           }
         }
+      if (L.ww_off >= 0) {  // F(2,3) along x: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2 per (dy, cin, cout)
+        float* dw = h->packed_host.data() + L.ww_off;
+        for (int dy = 0; dy < 3; ++dy)
+          for (size_t kc = 0; kc < nkc; ++kc) {
+            const float* rows[3][16];
+            for (int dx = 0; dx < 3; ++dx)
+              for (int j = 0; j < 16; ++j) {
+                const int ref = L.perm[kc * 16 + j];
+                rows[dx][j] = ref < 0 ? nullptr : src + ((size_t)(dy * 3 + dx) * L.cin + ref) * L.cout;
+              }
+            for (int co = 0; co < L.cout; ++co) {
+              float u[4][16];
+              for (int j = 0; j < 16; ++j) {
+                const float g0 = rows[0][j] ? rows[0][j][co] : 0.f, g1 = rows[1][j] ? rows[1][j][co] : 0.f,
+                            g2 = rows[2][j] ? rows[2][j][co] : 0.f;
+                u[0][j] = g0; u[1][j] = ((g0 + g2) + g1) * 0.5f; u[2][j] = ((g0 + g2) - g1) * 0.5f; u[3][j] = g2;
+              }
+              for (int nu = 0; nu < 4; ++nu)
+                memcpy(dw + (((size_t)co * nkc + kc) * 12 + nu * 3 + dy) * 16, u[nu], sizeof(u[nu]));
+            }
+          }
+      }
     } else
     for (int tap = 0; tap < L.kh * L.kw; ++tap)
       for (int ci = 0; ci < ct; ++ci) {
@@ -1182,6 +1222,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
   else if (!strcmp(key, "tune_ms")) h->opt_tune_ms = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "winograd")) {
+    if (value < 0 || value > 2) return fail(h, FILM_ERR_INVALID, "winograd: 0, 1 or 2");
+    if ((int)value != h->opt_wino) {  // plans carry the kernel choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_wino = (int)value;
+    }
+  }
   else if (!strcmp(key, "halo_all")) {
     if ((value != 0) != (h->opt_halo_all != 0)) {  // plans carry the kernel choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }

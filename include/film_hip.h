@@ -130,6 +130,10 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
  *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
  *                  (default 1); ordering between the two comes from a buffer-overlap analysis of the plan
+ *   "winograd" w   1 (default): 3x3 convolutions with Cout % 128 == 0 on the large pyramid levels use the 1-D
+ *                  Winograd transform F(2,3) along x (1.5x fewer fp32 multiplies; fp32 throughout, the rounding
+ *                  differs from the direct sum at the 1e-6 level).  0: direct kernels only.  2: every eligible
+ *                  3x3 convolution (tests).  Changing it drops the cached plans.
  *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.

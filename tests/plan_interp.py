@@ -70,6 +70,14 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 assert np.array_equal(wh, wt), 'halo weight copy differs'
                 if op.get('halo') or op.get('split'):
                     assert ks == 3 and not any(sg['up'] for sg in op['segs'])
+            if op.get('ww_off', -1) >= 0:
+                # Winograd copy [Cout][chunk][nu*3+dy][16]: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2
+                ww = packed[op['ww_off']:op['ww_off'] + 12 * ct * co].reshape(co, ct // 16, 4, 3, 16)
+                ww = ww.transpose(2, 3, 1, 4, 0).reshape(4, 3, ct, co)      # [nu][dy][c][n]
+                g0, g1, g2 = wt[:, 0], wt[:, 1], wt[:, 2]                    # [dy][c][n]
+                half = np.float32(0.5)
+                want_u = np.stack([g0, ((g0 + g2) + g1) * half, ((g0 + g2) - g1) * half, g2])
+                assert np.array_equal(ww, want_u), 'Winograd weight copy differs'
             if op.get('ws_off', -1) >= 0:
                 # bf16x6 copy: three bf16 planes [Cout][chunk][tap][plane][16] that add up to the weight EXACTLY
                 n16 = 9 * ct * co * 3

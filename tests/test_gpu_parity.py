@@ -278,6 +278,24 @@ def test_halo_kernels_on_every_level(published, precision, b, h, w):
     eng.close()
 
 
+@pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192)])
+def test_winograd_kernel_on_every_level(published, b, h, w):
+    """winograd = 2 forces conv_wino_kernel (F(2,3) along x) onto every 3x3 convolution with Cout % 64 == 0, i.e.
+    onto ragged patches (W < 64, odd pair counts, H not a multiple of 4): stage-by-stage parity with the oracle."""
+    from film_hip.engine import FilmEngine
+    opt, wts, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(wts)
+    eng.set_option('winograd', 2)
+    plan = eng.plan(b, h, w)
+    assert sum(op['wino'] for op in plan['ops']) > 30
+    x0, x1 = _pair(b, h, w, seed=53 + h + w)
+    _check_stages(eng, opt, wts, x0, x1)
+    eng.set_option('winograd', 0)
+    assert sum(op['wino'] for op in eng.plan(b, h, w)['ops']) == 0
+    eng.close()
+
+
 def test_errors(published):
     from film_hip.engine import FilmError
     opt, w, eng = published

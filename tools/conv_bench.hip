@@ -16,7 +16,7 @@
 #include "../frame-interpolation_amd/csrc/conv_igemm_impl.h"
 #include "experiments/conv_dma_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_split_impl.h"
-#include "experiments/conv_wino_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_wino_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_halo_impl.h"
 
