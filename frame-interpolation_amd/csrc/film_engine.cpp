@@ -395,9 +395,9 @@ struct Planner {
     op.split = h->opt_precision == 1 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all);
     // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M
     op.wino = !op.split && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
-              ((L.cout % 128 == 0 && px >= 8192) || (L.cout % 64 == 0 && ctot >= 192 && px >= 100000) || h->opt_wino == 2);
+              ((L.cout % 128 == 0 && px >= 8192) || (L.cout % 64 == 0 && px >= 100000) || h->opt_wino == 2);
     if (op.split || op.wino) op.halo = 0;
-    op.tile = op.wino ? ((L.cout % 128 == 0 ? WINO_4x128 : WINO_4x64) | CONV_TILE_WINO | CONV_TILE_XCD)
+    op.tile = op.wino ? ((L.cout % 128 == 0 ? WINO_4x128 : WINO_4x64_W8) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
@@ -760,7 +760,8 @@ std::vector<int> halo_candidates(int Cout) {
 }
 
 std::vector<int> wino_candidates(int Cout) {
-  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x128, WINO_4x64, WINO_2x128} : std::vector<int>{WINO_4x64};
+  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x128, WINO_4x64_W8, WINO_4x64, WINO_2x128}
+                                            : std::vector<int>{WINO_4x64_W8, WINO_4x64};
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_XCD); }
   return out;

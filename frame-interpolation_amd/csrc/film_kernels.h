@@ -141,7 +141,8 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                 CONV_TILE_SPLIT = 128 /* conv_halo_split_kernel (precision mode bf16x6): shape index = HaloTile,
                                          weights [Cout][chunk][tap][3 planes][16] bf16 */ };
 // conv_wino_kernel tiles: patch rows x 64 pixels x output channels (waves M x N)
-enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_2x128 = 2 /* 2x2 */, WINO_SHAPES = 3 };
+enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_2x128 = 2 /* 2x2 */, WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */,
+                WINO_SHAPES = 4 };
 // conv_halo_kernel tiles: patch rows x 32 pixels x output channels (waves M x N)
 enum HaloTile { HALO_8x128 = 0 /* 4x2 */, HALO_8x64 = 1 /* 4x1 */, HALO_8x32 = 2 /* 4x1 */, HALO_4x64 = 3 /* 4x1 */,
                 HALO_4x128 = 4 /* 2x2 */, HALO_4x32 = 5 /* 4x1 */, HALO_SHAPES = 6 };

@@ -60,7 +60,7 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
     V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4),
-    W(4, 128, 4, 2), W(4, 64, 4, 1), W(2, 128, 2, 2), W(2, 64, 2, 1), W(4, 32, 4, 1),
+    W(4, 128, 4, 2), W(4, 64, 4, 1), W(4, 64, 4, 2), W(2, 128, 2, 2), W(4, 32, 4, 1),
     S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
     H(4, 128, 2, 2, 4), H(8, 64, 2, 2, 4), B(256, 64, 4, 1, 4), B(128, 64, 2, 2, 4), B(64, 64, 2, 2, 4),
@@ -134,6 +134,8 @@ static Shape shapes[] = {
     {"feat_conv1  M=4.4M   C=64->64 3x3", 8, 576, 960, 64, 64, 3},
     {"flow_l0_c0  M=4.4M   C=128->32 3x3", 8, 576, 960, 128, 32, 3},
     {"ragged      36x60    C=64->64 3x3", 3, 36, 60, 64, 64, 3},
+    {"fusion_0_1  M=2.2M   C=208->64 3x3", 4, 576, 960, 208, 64, 3},
+    {"flow_l1_c0  M=1.1M   C=384->64 3x3", 8, 288, 480, 384, 64, 3},
     {"fusion_3_1  M=34560  C=2448->512 3x3", 4, 72, 120, 2448, 512, 3},
     {"flow_l3_c0  M=69120  C=1920->256 3x3", 8, 72, 120, 1920, 256, 3},
 };
