@@ -153,9 +153,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_kernel(ConvParams p) 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // ---- fragment addresses (float indices) ---------------------------------------------------------------
+  // ---- fragment addresses, in float4 units (indexing a bf4 array is what lets hipcc emit ds_read_b128: with float
+  // indices it cannot prove the 16-byte alignment and falls back to pairs of ds_read2_b32 - 50-70 % bank-conflict
+  // cycles measured) ------------------------------------------------------------------------------------------
   // A: LDS row (wy + mt + dy) * 40 + (l31 + dx); its swizzle term is ((l31 + dx) >> 2 & 3) ^ 2 * ((wy+mt+dy) & 1),
   // so K-half kq of that row is K-half kq ^ ((wy+mt+dy) & 1) of the base address.
+  const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
+  constexpr int A_STAGE4 = A_STAGE / 4, B_STAGE4 = B_STAGE / 4;
   const int wy = wm * TM;
   int a_ad[3][2];
 #pragma unroll
@@ -164,13 +168,13 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_kernel(ConvParams p) 
     const int swx = (px >> 2) & 3;
 #pragma unroll
     for (int k = 0; k < 2; ++k)
-      a_ad[dx][k] = (wy * PITCH + px) * 16 + (((((k ^ (wy & 1)) << 1) | half) ^ swx) << 2);
+      a_ad[dx][k] = (wy * PITCH + px) * 4 + ((((k ^ (wy & 1)) << 1) | half) ^ swx);
   }
   int b_ad[2];
   {
     const int sw = (l31 >> 2) & 3;
-    b_ad[0] = (wn * WTN + l31) * 16 + ((half ^ sw) << 2);
-    b_ad[1] = (wn * WTN + l31) * 16 + (((2 | half) ^ sw) << 2);
+    b_ad[0] = 2 * A_STAGE4 + (wn * WTN + l31) * 4 + (half ^ sw);
+    b_ad[1] = 2 * A_STAGE4 + (wn * WTN + l31) * 4 + ((2 | half) ^ sw);
   }
 
   int a_cur[3][2];  // a_ad + offset of the A stage being read
@@ -180,18 +184,17 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_kernel(ConvParams p) 
   auto compute = [&](auto tap_c) {
     constexpr int TAP = decltype(tap_c)::value;
     constexpr int DY = TAP / 3, DX = TAP % 3;
-    const float* Bs = Bsm + (TAP % 3) * B_STAGE;
     bf4 a[2][TM], b[2][TN];
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
       const int par = (mt + DY) & 1;
-      a[0][mt] = *reinterpret_cast<const bf4*>(smem + a_cur[DX][par] + (mt + DY) * PITCH * 16);
-      a[1][mt] = *reinterpret_cast<const bf4*>(smem + a_cur[DX][par ^ 1] + (mt + DY) * PITCH * 16);
+      a[0][mt] = smem4[a_cur[DX][par] + (mt + DY) * PITCH * 4];
+      a[1][mt] = smem4[a_cur[DX][par ^ 1] + (mt + DY) * PITCH * 4];
     }
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
-      b[0][nt] = *reinterpret_cast<const bf4*>(Bs + b_ad[0] + nt * 512);
-      b[1][nt] = *reinterpret_cast<const bf4*>(Bs + b_ad[1] + nt * 512);
+      b[0][nt] = smem4[b_ad[0] + (TAP % 3) * B_STAGE4 + nt * 128];
+      b[1][nt] = smem4[b_ad[1] + (TAP % 3) * B_STAGE4 + nt * 128];
     }
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq)
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_kernel(ConvParams p) 
     next_chunk(kc + 2);
     a_off = a_off ? 0 : A_STAGE;
 #pragma unroll
-    for (int dx = 0; dx < 3; ++dx) { a_cur[dx][0] = a_ad[dx][0] + a_off; a_cur[dx][1] = a_ad[dx][1] + a_off; }
+    for (int dx = 0; dx < 3; ++dx) { a_cur[dx][0] = a_ad[dx][0] + a_off / 4; a_cur[dx][1] = a_ad[dx][1] + a_off / 4; }
   }
 
   // ---- epilogue: bias + leaky_relu, 128-B row stores -------------------------------------------------

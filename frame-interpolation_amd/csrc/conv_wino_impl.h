@@ -169,29 +169,32 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_wino_kernel(ConvParams p) 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][v][j][r] = 0.f;
 
-  // ---- fragment addresses (float indices) -------------------------------------------------------------------
+  // ---- fragment addresses, in float4 units (a bf4-array index is what lets hipcc prove the 16-byte alignment and emit
+  // ds_read_b128 instead of pairs of ds_read2_b32) -------------------------------------------------------------
+  const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
+  constexpr int A_STAGE4 = A_STAGE / 4, B_STAGE4 = B_STAGE / 4;
   const int wy = wm * TM;
   const int sw = (l31 >> 2) & 3;
-  const int a_ad0 = (wy * 4 * 32 + l31) * 16 + ((half ^ sw) << 2);        // + ((mt + dy) * 4 + nu) * 512
-  const int a_ad1 = (wy * 4 * 32 + l31) * 16 + (((2 | half) ^ sw) << 2);
-  const int b_ad0 = (wn * WTN + l31) * 16 + ((half ^ sw) << 2);
-  const int b_ad1 = (wn * WTN + l31) * 16 + (((2 | half) ^ sw) << 2);
+  const int a_ad0 = (wy * 4 * 32 + l31) * 4 + (half ^ sw);        // + ((mt + dy) * 4 + nu) * 128
+  const int a_ad1 = (wy * 4 * 32 + l31) * 4 + ((2 | half) ^ sw);
+  const int b_ad0 = 2 * A_STAGE4 + (wn * WTN + l31) * 4 + (half ^ sw);
+  const int b_ad1 = 2 * A_STAGE4 + (wn * WTN + l31) * 4 + ((2 | half) ^ sw);
   int a_cur0 = a_ad0, a_cur1 = a_ad1;
 
   auto compute = [&](auto step_c) {
     constexpr int STEP = decltype(step_c)::value;   // nu * 3 + dy
     constexpr int NU = STEP / 3, DY = STEP % 3;
-    const float* Bs = Bsm + (NU & 1) * B_STAGE + DY * BN * 16;   // 4 macro steps per chunk: the stage parity is static
+    constexpr int BOFF = (NU & 1) * B_STAGE4 + DY * BN * 4;   // 4 macro steps per chunk: the stage parity is static
     bf4 a[2][TM], b[2][TN];
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) {
-      a[0][mt] = *reinterpret_cast<const bf4*>(smem + a_cur0 + ((mt + DY) * 4 + NU) * 512);
-      a[1][mt] = *reinterpret_cast<const bf4*>(smem + a_cur1 + ((mt + DY) * 4 + NU) * 512);
+      a[0][mt] = smem4[a_cur0 + ((mt + DY) * 4 + NU) * 128];
+      a[1][mt] = smem4[a_cur1 + ((mt + DY) * 4 + NU) * 128];
     }
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) {
-      b[0][nt] = *reinterpret_cast<const bf4*>(Bs + b_ad0 + nt * 512);
-      b[1][nt] = *reinterpret_cast<const bf4*>(Bs + b_ad1 + nt * 512);
+      b[0][nt] = smem4[b_ad0 + BOFF + nt * 128];
+      b[1][nt] = smem4[b_ad1 + BOFF + nt * 128];
     }
 #pragma unroll
     for (int kq = 0; kq < 2; ++kq)
@@ -235,8 +238,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_wino_kernel(ConvParams p) 
     macro(std::integral_constant<int, 3>{});
     next_chunk(kc + 2);
     a_stage ^= 1;
-    a_cur0 = a_ad0 + a_stage * A_STAGE;
-    a_cur1 = a_ad1 + a_stage * A_STAGE;
+    a_cur0 = a_ad0 + a_stage * A_STAGE4;
+    a_cur1 = a_ad1 + a_stage * A_STAGE4;
   }
 
   // ---- epilogue: output transform, bias + leaky_relu, 128-B row stores ---------------------------------

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/${TAG}_rocprof
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_rocprof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${TAG}_rocprof -o bench -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-split > $R/gpurun_out/${TAG}_rocprof.log 2>&1
 echo "kernel-trace rc=$?"
 cd $R
 python tools/rocprof_summary.py $(ls gpurun_out/${TAG}_rocprof/*/*results.db gpurun_out/${TAG}_rocprof/*results.db 2>/dev/null | head -1) --forwards 5 > gpurun_out/${TAG}_kernel_stats.md 2> gpurun_out/${TAG}_kernel_stats.err
