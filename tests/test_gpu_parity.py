@@ -296,6 +296,23 @@ def test_winograd_kernel_on_every_level(published, b, h, w):
     eng.close()
 
 
+def test_4k_frame_crosses_the_4gib_buffer_rule(published):
+    """BASELINE configs[4] geometry: a 3840x2160 pair with 4x4 blocks = 16 tiles of 960x576.  One model invocation may
+    hold at most floor(4 GiB / largest activation buffer) tiles (13 here), so film_interpolate runs two chunks; the
+    result must be bit-identical to running the tiles four at a time."""
+    opt, w, eng = published
+    rng = np.random.default_rng(59)
+    small = rng.random((1, 135, 240, 3), dtype=np.float32)
+    x0 = np.repeat(np.repeat(small, 16, axis=1), 16, axis=2)            # 2160 x 3840, blocky but not constant
+    x1 = np.roll(x0, (5, -7), axis=(1, 2)).copy()
+    a = eng.interpolate_frames(x0, x1, align=64, block_shape=[4, 4])
+    assert a.shape == (1, 2160, 3840, 3) and np.isfinite(a).all()
+    eng.set_option('max_batch', 4)
+    b = eng.interpolate_frames(x0, x1, align=64, block_shape=[4, 4])
+    eng.set_option('max_batch', 0)
+    assert np.array_equal(a, b)
+
+
 def test_errors(published):
     from film_hip.engine import FilmError
     opt, w, eng = published
