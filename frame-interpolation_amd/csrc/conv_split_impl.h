@@ -12,8 +12,10 @@
 //   * activations stay fp32 in HBM; the split happens once per staged element on the way into LDS (the halo
 //     staging amortises it over the nine taps); weights are split once on the host side:
 //     [Cout][chunk][tap][plane][16] bf16.
-//   * LDS rows are 112 B: 3 planes x 16 bf16 (96 B) + 16 B pad, i.e. 7 sixteen-byte units - odd, so 16 consecutive
-//     rows hit 16 distinct bank quads and the ds_read_b128 fragment reads need no swizzle.
+//   * LDS image, plane major: [plane][row][16 bf16 = 32 B]; the two 16-byte K-halves of row r are swapped when bit 3 of
+//     r is set.  Reads: the 16 rows of a ds_read_b128 lane group then hit 16 distinct bank quads (rows r and r+8 /
+//     r+24 would collide otherwise); writes: 4 rows x 32 contiguous bytes per 16-lane ds_write_b64 group.  (The first
+//     version used 112-byte [row][plane] rows: conflict-free reads, but 20-29 % conflict cycles from the stores.)
 #pragma once
 #include "conv_buf_impl.h"
 
@@ -50,9 +52,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
   constexpr int TM = TH / WGM;
   constexpr int WTN = BN / WGN, TN = WTN / 32;
   constexpr int HR = TH + 2, HC = 34;
-  constexpr int ROWB = 112;                      // bytes per LDS row
-  constexpr int A_STAGE = HR * HC * ROWB;        // bytes
-  constexpr int B_STAGE = BN * ROWB;
+  constexpr int A_PLANE = HR * HC * 32;          // bytes: one bf16 plane of the halo chunk
+  constexpr int B_PLANE = BN * 32;
+  constexpr int A_STAGE = 3 * A_PLANE;           // bytes
+  constexpr int B_STAGE = 3 * B_PLANE;
   constexpr int HF4 = HR * HC * 4;
   constexpr int AH = (HF4 + NT - 1) / NT;
   constexpr int BU = BN * 6;                     // 16-byte units of one weight step
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
     const int hy = r / HC, hx = r - hy * HC;
     aiy[i] = y0 - 1 + hy; aix[i] = x0 - 1 + hx;
     ain[i] = slot && aiy[i] >= 0 && aiy[i] < p.H && aix[i] >= 0 && aix[i] < p.W;
-    alds[i] = slot ? r * ROWB + ch * 8 : -1;
+    alds[i] = slot ? r * 32 + ((((ch >> 1) ^ ((r >> 3) & 1)) << 4) | ((ch & 1) << 3)) : -1;
   }
   const int scol = (t & 3) * 4;
   unsigned aoff[AH];
@@ -124,11 +127,11 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
   int blds[BLD];
 #pragma unroll
   for (int i = 0; i < BLD; ++i) {
-    const int u = t + NT * i;
+    const int u = t + NT * i;   // (plane, row, K-half): 8 consecutive lanes store 4 rows x 32 contiguous bytes
     const bool slot = u < BU;
-    const int row = slot ? u / 6 : 0, q = slot ? u - row * 6 : 0;
-    boff[i] = (unsigned)((size_t)(n0 + row) * nsteps * 96 + q * 16);
-    blds[i] = slot ? row * ROWB + q * 16 : -1;
+    const int kb = u & 1, row = slot ? (u >> 1) % BN : 0, pl = slot ? (u >> 1) / BN : 0;
+    boff[i] = (unsigned)((size_t)(n0 + row) * nsteps * 96 + pl * 32 + kb * 16);
+    blds[i] = slot ? pl * B_PLANE + row * 32 + ((kb ^ ((row >> 3) & 1)) << 4) : -1;
   }
 
   bf4 areg[AH];
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
         su2 hi, mid, lo;
         conv_split4(areg[i], hi, mid, lo);
         *reinterpret_cast<su2*>(As + alds[i]) = hi;
-        *reinterpret_cast<su2*>(As + alds[i] + 32) = mid;
-        *reinterpret_cast<su2*>(As + alds[i] + 64) = lo;
+        *reinterpret_cast<su2*>(As + alds[i] + A_PLANE) = mid;
+        *reinterpret_cast<su2*>(As + alds[i] + 2 * A_PLANE) = lo;
       }
     }
   };
@@ -180,24 +183,38 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // fragment addresses in 16-byte units (su4 array index -> ds_read_b128).  A: row (wy+mt+dy)*34 + dx + l31, one
+  // address per (row of the wave, tap) because the K-half swap depends on bit 3 of the row.
+  const su4* const smem16 = reinterpret_cast<const su4*>(smem_b);
   const int wy = wm * TM;
-  const int a_base = (wy * HC + l31) * ROWB + half * 16;               // + (mt+dy)*HC*ROWB + dx*ROWB + plane*32
-  const int b_base = (wn * WTN + l31) * ROWB + half * 16;              // + nt*32*ROWB + plane*32
-  int a_cur = a_base;
+  int a_ad[TM + 2][3];
+#pragma unroll
+  for (int ry = 0; ry < TM + 2; ++ry)
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      const int r = (wy + ry) * HC + dx + l31;
+      a_ad[ry][dx] = r * 2 + (half ^ ((r >> 3) & 1));
+    }
+  int b_ad[TN];
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt) {
+    const int r = wn * WTN + nt * 32 + l31;
+    b_ad[nt] = (2 * A_STAGE) / 16 + r * 2 + (half ^ ((r >> 3) & 1));
+  }
+  int a_stage_u = 0;  // 16-byte offset of the A stage being read
 
   auto compute = [&](auto tap_c) {
     constexpr int TAP = decltype(tap_c)::value;
     constexpr int DY = TAP / 3, DX = TAP % 3;
-    const unsigned char* Bs = Bsm + (TAP % 3) * B_STAGE;
     sbf8 a[3][TM], b[3][TN];
 #pragma unroll
     for (int pl = 0; pl < 3; ++pl) {
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
-        a[pl][mt] = __builtin_bit_cast(sbf8, *reinterpret_cast<const su4*>(smem_b + a_cur + ((mt + DY) * HC + DX) * ROWB + pl * 32));
+        a[pl][mt] = __builtin_bit_cast(sbf8, smem16[a_ad[mt + DY][DX] + a_stage_u + pl * (A_PLANE / 16)]);
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt)
-        b[pl][nt] = __builtin_bit_cast(sbf8, *reinterpret_cast<const su4*>(Bs + b_base + nt * 32 * ROWB + pl * 32));
+        b[pl][nt] = __builtin_bit_cast(sbf8, smem16[b_ad[nt] + (TAP % 3) * (B_STAGE / 16) + pl * (B_PLANE / 16)]);
     }
     // smallest partial products first
     constexpr int PA[6] = {1, 0, 2, 0, 1, 0};
@@ -245,7 +262,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
     step(std::integral_constant<int, 8>{});
     next_chunk(kc + 2);
     a_stage ^= 1;
-    a_cur = a_base + a_stage * A_STAGE;
+    a_stage_u = a_stage * (A_STAGE / 16);
   }
 
 #pragma unroll
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
 
 template <int TH, int BN, int WGM, int WGN, int NPROD, int FLAGS>
 hipError_t conv_halo_split_launch(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = 2 * (size_t)(TH + 2) * 34 * 112 + 3 * (size_t)BN * 112;
+  constexpr size_t lds = 2 * 3 * (size_t)(TH + 2) * 34 * 32 + 3 * 3 * (size_t)BN * 32;
   auto kern = conv_halo_split_kernel<TH, BN, WGM, WGN, NPROD, FLAGS>;
   if constexpr (lds > 64 * 1024) {
     static bool attr_set = false;
