@@ -84,7 +84,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
   const int pcol = ((t & 3) ^ ((t >> 4) & 3)) * 4;  // swizzled position inside the LDS row (RPP % 16 == 0)
   const int ksz = p.ksize;
   const int pad = (ksz - 1) >> 1;
-  const int ntaps = ksz * ksz;
+  const int ntaps = p.fold ? p.ftaps : ksz * ksz;
+  auto tap_dy = [&](int tp) { return p.fold ? (int)p.tdy[tp] : tp / ksz - pad; };
+  auto tap_dx = [&](int tp) { return p.fold ? (int)p.tdx[tp] : tp % ksz - pad; };
   const int HW = p.H * p.W;
   int ab[AR], ay[AR], ax[AR];
   unsigned amask[AR];                      // bit tap: the tap's source pixel is inside the image (and m < M)
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
     ab[i] = b; ay[i] = y; ax[i] = x;
     unsigned mask = 0;
     for (int tp = 0; tp < ntaps; ++tp) {
-      const int yy = y + tp / ksz - pad, xx = x + tp % ksz - pad;
+      const int yy = y + tap_dy(tp), xx = x + tap_dx(tp);
       if (valid && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) mask |= 1u << tp;
     }
     amask[i] = mask;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
   };
   auto setup_tap = [&]() {
     const ConvSeg& s = p.seg[sg];
-    const int dy = tap / ksz - pad, dx = tap % ksz - pad;
+    const int dy = tap_dy(tap), dx = tap_dx(tap);
     if (!s.up) {
       const unsigned delta = (unsigned)((dy * p.W + dx) * s.stride * 4);
 #pragma unroll
@@ -266,7 +268,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
         if (m < p.M) {
           float v = acc[mt][nt][r] + bv;
           if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-          p.out[(size_t)m * p.ostride + n] = v;
+          size_t opix = (size_t)m;
+          if (p.fold) {  // low-resolution pixel (b, y, x) -> output pixel (b, 2y+py, 2x+px) of the 2H x 2W image
+            const int b = m / HW, rr = m - b * HW, y = rr / p.W, x = rr - y * p.W;
+            opix = ((size_t)b * 2 * p.H + 2 * y + p.py) * (2 * p.W) + 2 * x + p.px;
+          }
+          p.out[opix * p.ostride + n] = v;
         }
       }
     }

@@ -67,6 +67,8 @@ struct OpDesc {
   int64_t w2_off = 0, b2_off = 0;     // flow_head: second 1x1 conv
   int64_t wh_off = -1;                // conv: the layer's conv_halo_kernel weight copy (-1: none)
   int64_t ws_off = -1;                // conv: the layer's bf16x6 weight copy
+  int fold = 0, py = 0, px = 0;       // conv: sub-pixel phase of a folded upsample + 2x2 conv (H, W = low-res grid)
+  int ftaps = 0; int tdy[4] = {0, 0, 0, 0}, tdx[4] = {0, 0, 0, 0};
   int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
   int wino = 0;                       // conv: runs on conv_wino_kernel
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
@@ -93,10 +95,13 @@ struct LayerPack {
   bool kmajor() const { return !c3 && cout % 32 == 0; }
   int64_t w_off = 0, b_off = 0;
   int64_t wh_off = -1;       // 3x3 K-major layers: second copy packed for conv_halo_kernel, [Cout][ctot/16][9][16]
+  int64_t wf_off = -1;       // 2x2 layers behind a nearest upsample: the four sub-pixel phases, pre-summed weights,
+                             //     phase (py,px) at wf_off + fold_phase_off(py,px): [Cout][ntaps_p * ctot], 9*ctot*cout in all
   int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/16][12][16]
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
                              //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
+  bool has_fold() const { return kmajor() && kh == 2 && kw == 2; }
   int ctot() const { return (int)perm.size(); }
   int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
 };
@@ -146,6 +151,7 @@ struct film_handle {
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd F(2,3) kernel where measured faster (default), 2: every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
   int opt_tune_ms = 0;    // autotune: minimum kernel time spent per candidate (0: two launches)
@@ -297,6 +303,7 @@ void build_layers(film_t* h) {
     L.b_off = off;
     off += L.cout;
     off = (off + 3) & ~int64_t(3);
+    if (L.has_fold()) { L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; off = (off + 3) & ~int64_t(3); }
     if (L.has_halo()) {
       L.wh_off = off; off += L.packed_rows() * L.cout;
       off = (off + 3) & ~int64_t(3);
@@ -377,6 +384,32 @@ struct Planner {
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
     op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off;
+    if (h->opt_fold && L.wf_off >= 0 && op.nseg == 1 && segs[0].up && !(H & 1) && !(W & 1)) {
+      // nearest x2 + 2x2 'same' conv == four phase convolutions on the low-resolution input: kernel tap (dy, dx) of
+      // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
+      // (0,0) has ONE distinct input pixel, (0,1) and (1,0) two, (1,1) four: 9 taps per 4 outputs instead of 16.
+      // The weights of taps that read the same pixel are summed at film_finalize (exact regrouping of the sum).
+      int64_t woff = L.wf_off;
+      for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+          OpDesc f = op;
+          f.tag = op.tag + ":phase" + std::to_string(py) + std::to_string(px);
+          f.fold = 1; f.py = py; f.px = px; f.ftaps = 0;
+          for (int a = 0; a <= py; ++a)
+            for (int b = 0; b <= px; ++b) { f.tdy[f.ftaps] = a; f.tdx[f.ftaps] = b; ++f.ftaps; }
+          f.seg[0].up = 0;
+          f.out = out; f.NB = NB;
+          f.H = H / 2; f.W = W / 2;
+          f.w_off = woff;
+          woff += (int64_t)f.ftaps * ctot * L.cout;
+          f.halo = f.split = f.wino = 0;
+          f.tile = choose_tile((int64_t)NB * f.H * f.W, L.cout);
+          f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin / 4;   // algorithmic FLOPs of the reference op
+          f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout) / 4;
+          P->ops.push_back(f);
+        }
+      return;
+    }
     op.out = out; op.NB = NB; op.H = H; op.W = W;
     const int64_t M = (int64_t)NB * H * W;
     // Kernel family by layer shape only (never by timing, and not by the batch size): the two kernels sum K in a
@@ -698,6 +731,8 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
       p.M = op.NB * op.H * op.W;
+      p.fold = op.fold; p.py = op.py; p.px = op.px; p.ftaps = op.ftaps;
+      for (int q = 0; q < 4; ++q) { p.tdy[q] = (signed char)op.tdy[q]; p.tdx[q] = (signed char)op.tdx[q]; }
       return film_launch_conv(p, op.tile, s);
     }
     case OP_FLOW_HEAD: {
@@ -785,7 +820,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << op.py << op.px;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -937,7 +972,9 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wino\":" << op.wino << ",\"lane\":" << op.lane << ",\"xdeps\":["
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
+      << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
+      << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
       << [&] { std::string d; for (size_t q = 0; q < op.xdeps.size(); ++q) d += (q ? "," : "") + std::to_string(op.xdeps[q]); return d; }() << "]" << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
       << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
@@ -1145,6 +1182,29 @@ int film_finalize(film_t* h) {
             }
           }
         }
+      if (L.wf_off >= 0) {  // sub-pixel phases of upsample + 2x2: weights of the taps that read the same input pixel, summed
+        float* df = h->packed_host.data() + L.wf_off;
+        for (int py = 0; py < 2; ++py)
+          for (int px = 0; px < 2; ++px) {
+            const int nt = (py + 1) * (px + 1);
+            const size_t kph = (size_t)nt * ct;
+            int t = 0;
+            for (int a = 0; a <= py; ++a)
+              for (int b = 0; b <= px; ++b, ++t)
+                for (int ci = 0; ci < ct; ++ci) {
+                  const int ref = L.perm[ci];
+                  if (ref < 0) continue;
+                  for (int co = 0; co < L.cout; ++co) {
+                    float acc = 0.f;  // kernel taps (dy, dx) with (py & dy) == a and (px & dx) == b, in raster order
+                    for (int dy = 0; dy < 2; ++dy)
+                      for (int dx = 0; dx < 2; ++dx)
+                        if ((py & dy) == a && (px & dx) == b) acc += src[((size_t)(dy * 2 + dx) * L.cin + ref) * L.cout + co];
+                    df[(size_t)co * kph + (size_t)t * ct + ci] = acc;
+                  }
+                }
+            df += kph * L.cout;
+          }
+      }
       if (L.ww_off >= 0) {  // F(2,3) along x: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2 per (dy, cin, cout)
         float* dw = h->packed_host.data() + L.ww_off;
         for (int dy = 0; dy < 3; ++dy)
@@ -1223,6 +1283,15 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
   else if (!strcmp(key, "tune_ms")) h->opt_tune_ms = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "fold2x2")) {
+    if ((value != 0) != (h->opt_fold != 0)) {  // plans carry the op list: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_fold = value != 0;
+    }
+  }
   else if (!strcmp(key, "winograd")) {
     if (value < 0 || value > 2) return fail(h, FILM_ERR_INVALID, "winograd: 0, 1 or 2");
     if ((int)value != h->opt_wino) {  // plans carry the kernel choice: drop them

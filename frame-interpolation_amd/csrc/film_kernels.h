@@ -39,6 +39,12 @@ struct ConvParams {
   int Cout, Ctot;
   int leaky;
   int M;
+  // Sub-pixel fold of nearest-x2-upsample + 2x2 conv (fusion.py:133-135), conv_buf_kernel only.  fold = 1: the
+  // launch computes output phase (py, px), i.e. out[2y+py][2x+px] for every pixel (y, x) of the LOW-resolution input
+  // (H, W, M describe that grid; the output is 2H x 2W), from `ftaps` taps (tdy[t], tdx[t]) in {0,1}^2 of it, with
+  // weights [Cout][ftaps * Ctot] pre-summed over the kernel taps that read the same input pixel.
+  int fold, py, px, ftaps;
+  signed char tdy[4], tdx[4];
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,

@@ -130,6 +130,10 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
  *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
  *                  (default 1); ordering between the two comes from a buffer-overlap analysis of the plan
+ *   "fold2x2" 0/1  1 (default): the decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) runs as four
+ *                  sub-pixel phase convolutions on the low-resolution input with pre-summed weights (9 taps per 4
+ *                  outputs instead of 16; an exact regrouping of the sum, rounding differs at the 1e-7 level).
+ *                  0: one 2x2 convolution with the upsample folded into its gather.  Drops the cached plans.
  *   "winograd" w   1 (default): 3x3 convolutions with Cout % 128 == 0 on the large pyramid levels use the 1-D
  *                  Winograd transform F(2,3) along x (1.5x fewer fp32 multiplies; fp32 throughout, the rounding
  *                  differs from the direct sum at the 1e-6 level).  0: direct kernels only.  2: every eligible

@@ -44,6 +44,22 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             wt = np.ascontiguousarray(w48[:9, :3]).reshape(3, 3, 3, co)
             bias = packed[op['b_off']:op['b_off'] + co]
             _view(arena, op['out'], nb, h, w)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+        elif k == 'conv_mfma' and op.get('fold'):
+            # sub-pixel phase of nearest-x2 + 2x2 conv: H, W = the low-resolution grid, output 2H x 2W
+            sg = op['segs'][0]
+            assert len(op['segs']) == 1 and not sg['up'] and not sg['bmod']
+            x = np.ascontiguousarray(_view(arena, sg['v'], nb, h, w))
+            ct, co, nt = op['Ctot'], op['Cout'], op['ftaps']
+            wt = packed[op['w_off']:op['w_off'] + nt * ct * co].reshape(co, nt, ct)
+            acc = np.zeros((nb, h, w, co), np.float32)
+            for t in range(nt):
+                a, b = op['tdy'][t], op['tdx'][t]
+                sh = np.zeros_like(x)
+                sh[:, :h - a, :w - b] = x[:, a:, b:]          # zero beyond the bottom / right edge
+                acc += (sh.reshape(-1, ct) @ wt[:, t].T).reshape(nb, h, w, co)
+            acc += packed[op['b_off']:op['b_off'] + co]
+            assert not op['leaky']
+            _view(arena, op['out'], nb, 2 * h, 2 * w)[:, op['py']::2, op['px']::2] = acc
         elif k == 'conv_mfma':
             parts = []
             for sg in op['segs']:
