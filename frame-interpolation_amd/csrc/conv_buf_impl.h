@@ -84,9 +84,12 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
   const int pcol = ((t & 3) ^ ((t >> 4) & 3)) * 4;  // swizzled position inside the LDS row (RPP % 16 == 0)
   const int ksz = p.ksize;
   const int pad = (ksz - 1) >> 1;
-  const int ntaps = p.fold ? p.ftaps : ksz * ksz;
-  auto tap_dy = [&](int tp) { return p.fold ? (int)p.tdy[tp] : tp / ksz - pad; };
-  auto tap_dx = [&](int tp) { return p.fold ? (int)p.tdx[tp] : tp % ksz - pad; };
+  // folded upsample + 2x2 (film_kernels.h): phase from the params (fold = 1) or from blockIdx.z (fold = 2)
+  const int fpy = p.fold == 2 ? (int)(blockIdx.z >> 1) : p.py, fpx = p.fold == 2 ? (int)(blockIdx.z & 1) : p.px;
+  const int ntaps = p.fold == 2 ? (fpy + 1) * (fpx + 1) : p.fold ? p.ftaps : ksz * ksz;
+  auto tap_dy = [&](int tp) { return p.fold == 2 ? (fpx ? tp >> 1 : tp) : p.fold ? (int)p.tdy[tp] : tp / ksz - pad; };
+  auto tap_dx = [&](int tp) { return p.fold == 2 ? (fpx ? tp & 1 : 0) : p.fold ? (int)p.tdx[tp] : tp % ksz - pad; };
+  const float* const wbase = p.fold == 2 ? p.w + p.fold_woff[blockIdx.z] : p.w;
   const int HW = p.H * p.W;
   int ab[AR], ay[AR], ax[AR];
   unsigned amask[AR];                      // bit tap: the tap's source pixel is inside the image (and m < M)
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
     amask[i] = mask;
   }
   const int Ktot = ntaps * p.Ctot;
-  const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
+  const conv_rsrc_t brsrc = conv_make_rsrc(wbase);
   unsigned boff[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) boff[i] = (unsigned)(((n0 + (srow + RPP * i) % BN) * Ktot + scol) * 4);
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
           size_t opix = (size_t)m;
           if (p.fold) {  // low-resolution pixel (b, y, x) -> output pixel (b, 2y+py, 2x+px) of the 2H x 2W image
             const int b = m / HW, rr = m - b * HW, y = rr / p.W, x = rr - y * p.W;
-            opix = ((size_t)b * 2 * p.H + 2 * y + p.py) * (2 * p.W) + 2 * x + p.px;
+            opix = ((size_t)b * 2 * p.H + 2 * y + fpy) * (2 * p.W) + 2 * x + fpx;
           }
           p.out[opix * p.ostride + n] = v;
         }
@@ -292,7 +295,7 @@ hipError_t conv_buf_launch(const ConvParams& p, hipStream_t s) {
       attr_set = true;
     }
   }
-  dim3 grid((p.M + BM - 1) / BM, p.Cout / BN);
+  dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.fold == 2 ? 4 : 1);
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, p);
   return hipGetLastError();
 }

@@ -69,6 +69,7 @@ struct OpDesc {
   int64_t ws_off = -1;                // conv: the layer's bf16x6 weight copy
   int fold = 0, py = 0, px = 0;       // conv: sub-pixel phase of a folded upsample + 2x2 conv (H, W = low-res grid)
   int ftaps = 0; int tdy[4] = {0, 0, 0, 0}, tdx[4] = {0, 0, 0, 0};
+  int64_t fold_woff[4] = {0, 0, 0, 0};  // fold == 2: weight offset of phase q relative to w_off
   int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
   int wino = 0;                       // conv: runs on conv_wino_kernel
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
@@ -389,25 +390,21 @@ struct Planner {
       // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
       // (0,0) has ONE distinct input pixel, (0,1) and (1,0) two, (1,1) four: 9 taps per 4 outputs instead of 16.
       // The weights of taps that read the same pixel are summed at film_finalize (exact regrouping of the sum).
-      int64_t woff = L.wf_off;
-      for (int py = 0; py < 2; ++py)
-        for (int px = 0; px < 2; ++px) {
-          OpDesc f = op;
-          f.tag = op.tag + ":phase" + std::to_string(py) + std::to_string(px);
-          f.fold = 1; f.py = py; f.px = px; f.ftaps = 0;
-          for (int a = 0; a <= py; ++a)
-            for (int b = 0; b <= px; ++b) { f.tdy[f.ftaps] = a; f.tdx[f.ftaps] = b; ++f.ftaps; }
-          f.seg[0].up = 0;
-          f.out = out; f.NB = NB;
-          f.H = H / 2; f.W = W / 2;
-          f.w_off = woff;
-          woff += (int64_t)f.ftaps * ctot * L.cout;
-          f.halo = f.split = f.wino = 0;
-          f.tile = choose_tile((int64_t)NB * f.H * f.W, L.cout);
-          f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin / 4;   // algorithmic FLOPs of the reference op
-          f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout) / 4;
-          P->ops.push_back(f);
-        }
+      // One launch runs the four phases (blockIdx.z): 4x the blocks of a phase launch, better tails.
+      OpDesc f = op;
+      f.tag = op.tag + ":phases";
+      f.fold = 2;
+      f.seg[0].up = 0;
+      f.out = out; f.NB = NB;
+      f.H = H / 2; f.W = W / 2;
+      f.w_off = L.wf_off;
+      int64_t rel = 0;
+      for (int q = 0; q < 4; ++q) { f.fold_woff[q] = rel; rel += (int64_t)((q >> 1) + 1) * ((q & 1) + 1) * ctot * L.cout; }
+      f.halo = f.split = f.wino = 0;
+      f.tile = choose_tile((int64_t)NB * f.H * f.W * 2, L.cout);
+      f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin;   // algorithmic FLOPs of the reference op
+      f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout);
+      P->ops.push_back(f);
       return;
     }
     op.out = out; op.NB = NB; op.H = H; op.W = W;
@@ -732,7 +729,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
       p.M = op.NB * op.H * op.W;
       p.fold = op.fold; p.py = op.py; p.px = op.px; p.ftaps = op.ftaps;
-      for (int q = 0; q < 4; ++q) { p.tdy[q] = (signed char)op.tdy[q]; p.tdx[q] = (signed char)op.tdx[q]; }
+      for (int q = 0; q < 4; ++q) { p.tdy[q] = (signed char)op.tdy[q]; p.tdx[q] = (signed char)op.tdx[q]; p.fold_woff[q] = op.fold_woff[q]; }
       return film_launch_conv(p, op.tile, s);
     }
     case OP_FLOW_HEAD: {
@@ -820,7 +817,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << op.py << op.px;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -974,7 +971,8 @@ std::string plan_json(film_t* h, const Plan& P) {
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
       << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
-      << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
+      << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
+      << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
       << [&] { std::string d; for (size_t q = 0; q < op.xdeps.size(); ++q) d += (q ? "," : "") + std::to_string(op.xdeps[q]); return d; }() << "]" << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
       << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";

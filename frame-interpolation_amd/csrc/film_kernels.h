@@ -43,8 +43,11 @@ struct ConvParams {
   // launch computes output phase (py, px), i.e. out[2y+py][2x+px] for every pixel (y, x) of the LOW-resolution input
   // (H, W, M describe that grid; the output is 2H x 2W), from `ftaps` taps (tdy[t], tdx[t]) in {0,1}^2 of it, with
   // weights [Cout][ftaps * Ctot] pre-summed over the kernel taps that read the same input pixel.
+  // fold = 2: all four phases in ONE launch, phase = blockIdx.z = py*2 + px, taps (a, b) with a <= py, b <= px in
+  // raster order, weights of phase q at w + fold_woff[q] (py, px, ftaps, tdy, tdx are then ignored).
   int fold, py, px, ftaps;
   signed char tdy[4], tdx[4];
+  long long fold_woff[4];
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,

@@ -45,21 +45,25 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             bias = packed[op['b_off']:op['b_off'] + co]
             _view(arena, op['out'], nb, h, w)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
         elif k == 'conv_mfma' and op.get('fold'):
-            # sub-pixel phase of nearest-x2 + 2x2 conv: H, W = the low-resolution grid, output 2H x 2W
+            # nearest-x2 + 2x2 conv as four sub-pixel phases on the low-resolution grid (H, W); output 2H x 2W.
+            # fold == 2: all phases in one op, phase q = py*2 + px, taps (a, b), a <= py, b <= px, raster order
             sg = op['segs'][0]
-            assert len(op['segs']) == 1 and not sg['up'] and not sg['bmod']
+            assert op['fold'] == 2 and len(op['segs']) == 1 and not sg['up'] and not sg['bmod'] and not op['leaky']
             x = np.ascontiguousarray(_view(arena, sg['v'], nb, h, w))
-            ct, co, nt = op['Ctot'], op['Cout'], op['ftaps']
-            wt = packed[op['w_off']:op['w_off'] + nt * ct * co].reshape(co, nt, ct)
-            acc = np.zeros((nb, h, w, co), np.float32)
-            for t in range(nt):
-                a, b = op['tdy'][t], op['tdx'][t]
-                sh = np.zeros_like(x)
-                sh[:, :h - a, :w - b] = x[:, a:, b:]          # zero beyond the bottom / right edge
-                acc += (sh.reshape(-1, ct) @ wt[:, t].T).reshape(nb, h, w, co)
-            acc += packed[op['b_off']:op['b_off'] + co]
-            assert not op['leaky']
-            _view(arena, op['out'], nb, 2 * h, 2 * w)[:, op['py']::2, op['px']::2] = acc
+            ct, co = op['Ctot'], op['Cout']
+            outv = _view(arena, op['out'], nb, 2 * h, 2 * w)
+            for q in range(4):
+                py, px = q >> 1, q & 1
+                taps = [(a, b) for a in range(py + 1) for b in range(px + 1)]
+                off = op['w_off'] + op['fold_woff'][q]
+                wt = packed[off:off + len(taps) * ct * co].reshape(co, len(taps), ct)
+                acc = np.zeros((nb, h, w, co), np.float32)
+                for t, (a, b) in enumerate(taps):
+                    sh = np.zeros_like(x)
+                    sh[:, :h - a, :w - b] = x[:, a:, b:]          # zero beyond the bottom / right edge
+                    acc += (sh.reshape(-1, ct) @ wt[:, t].T).reshape(nb, h, w, co)
+                acc += packed[op['b_off']:op['b_off'] + co]
+                outv[:, py::2, px::2] = acc
         elif k == 'conv_mfma':
             parts = []
             for sg in op['segs']:
