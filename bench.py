@@ -206,6 +206,19 @@ def main():
         # conv_mfma launches carry all conv FLOPs except the Cin=3 first layer and the tiny 1x1 heads
         conv_tflops = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
         total_ms = sum(c['ms'] for c in cls.values())
+        # FLOPs the matrix pipe really executes: the Winograd F(2,3) kernel (tile id & 256) does 2/3 of the direct
+        # convolution's multiplies, the sub-pixel-folded upsample + 2x2 conv (tag ':phases') 9/16
+        exec_flops = 0.0
+        for o in prof['ops']:
+            if o['kind'] != 'conv_mfma':
+                continue
+            f = o['flops']
+            if o['tile'] & 256:
+                f *= 2.0 / 3.0
+            elif o['tag'].endswith(':phases'):
+                f *= 9.0 / 16.0
+            exec_flops += f
+        exec_tflops = exec_flops / (conv['ms'] * 1e-3) / 1e12
         traffic = None
         try:  # HBM-side bytes per conv launch from the committed PMC passes of this build (profiles/)
             import glob
@@ -227,6 +240,9 @@ def main():
             'algorithmic_flops_per_step': conv['flops'],
             'all_conv_flops_per_step': alg_flops,
             'share_of_kernel_time': round(conv['ms'] / total_ms, 4),
+            'executed': {'achieved': round(exec_tflops, 3), 'frac': round(exec_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+                         'note': 'FLOPs the matrix pipe executes (Winograd layers x2/3, folded 2x2 layers x9/16); `achieved` / '
+                                 '`frac` above count the direct convolution (SURVEY 8d) and can exceed the fp32 MFMA peak'},
         }
         extra = {}
         if 'warp' in cls:

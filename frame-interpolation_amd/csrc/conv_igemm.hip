@@ -88,7 +88,8 @@ static hipError_t launch_wino(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
     case WINO_4x128: return conv_wino_launch<4, 128, 4, 2, F>(p, s);
     case WINO_4x64: return conv_wino_launch<4, 64, 4, 1, F>(p, s);
-    case WINO_2x128: return conv_wino_launch<2, 128, 2, 2, F>(p, s);
+    case WINO_4x128_W16: return conv_wino_launch<4, 128, 4, 4, F>(p, s);
+    case WINO_4x32: return conv_wino_launch<4, 32, 4, 1, F>(p, s);
     case WINO_4x64_W8: return conv_wino_launch<4, 64, 4, 2, F>(p, s);
     default: return hipErrorInvalidValue;
   }

@@ -98,7 +98,7 @@ struct LayerPack {
   int64_t wh_off = -1;       // 3x3 K-major layers: second copy packed for conv_halo_kernel, [Cout][ctot/16][9][16]
   int64_t wf_off = -1;       // 2x2 layers behind a nearest upsample: the four sub-pixel phases, pre-summed weights,
                              //     phase (py,px) at wf_off + fold_phase_off(py,px): [Cout][ntaps_p * ctot], 9*ctot*cout in all
-  int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/16][12][16]
+  int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/8][12][8]
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
                              //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
@@ -310,7 +310,7 @@ void build_layers(film_t* h) {
       off = (off + 3) & ~int64_t(3);
       L.ws_off = off; off += (L.packed_rows() * L.cout * 3 + 1) / 2;
       off = (off + 3) & ~int64_t(3);
-      if (L.cout % 64 == 0) { L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12; }
+      L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12;
     }
     off = (off + 3) & ~int64_t(3);
   }
@@ -425,9 +425,9 @@ struct Planner {
     op.split = h->opt_precision == 1 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all);
     // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M
     op.wino = !op.split && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
-              ((L.cout % 128 == 0 && px >= 8192) || (L.cout % 64 == 0 && px >= 100000) || h->opt_wino == 2);
+              ((L.cout % 128 == 0 && px >= 8192) || px >= 100000 || h->opt_wino == 2);
     if (op.split || op.wino) op.halo = 0;
-    op.tile = op.wino ? ((L.cout % 128 == 0 ? WINO_4x128 : WINO_4x64_W8) | CONV_TILE_WINO | CONV_TILE_XCD)
+    op.tile = op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
@@ -792,8 +792,9 @@ std::vector<int> halo_candidates(int Cout) {
 }
 
 std::vector<int> wino_candidates(int Cout) {
-  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x128, WINO_4x64_W8, WINO_4x64, WINO_2x128}
-                                            : std::vector<int>{WINO_4x64_W8, WINO_4x64};
+  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_4x128_W16, WINO_4x128, WINO_4x64}
+                            : Cout % 64 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_4x64, WINO_4x32}
+                                             : std::vector<int>{WINO_4x32};
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_XCD); }
   return out;
@@ -1203,25 +1204,27 @@ int film_finalize(film_t* h) {
             df += kph * L.cout;
           }
       }
-      if (L.ww_off >= 0) {  // F(2,3) along x: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2 per (dy, cin, cout)
+      if (L.ww_off >= 0) {  // F(2,3) along x: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2 per (dy, cin, cout);
+                            // 8-channel chunks: [Cout][chunk8][nu*3+dy][8]
         float* dw = h->packed_host.data() + L.ww_off;
+        const size_t nk8 = (size_t)ct / 8;
         for (int dy = 0; dy < 3; ++dy)
-          for (size_t kc = 0; kc < nkc; ++kc) {
-            const float* rows[3][16];
+          for (size_t kc = 0; kc < nk8; ++kc) {
+            const float* rows[3][8];
             for (int dx = 0; dx < 3; ++dx)
-              for (int j = 0; j < 16; ++j) {
-                const int ref = L.perm[kc * 16 + j];
+              for (int j = 0; j < 8; ++j) {
+                const int ref = L.perm[kc * 8 + j];
                 rows[dx][j] = ref < 0 ? nullptr : src + ((size_t)(dy * 3 + dx) * L.cin + ref) * L.cout;
               }
             for (int co = 0; co < L.cout; ++co) {
-              float u[4][16];
-              for (int j = 0; j < 16; ++j) {
+              float u[4][8];
+              for (int j = 0; j < 8; ++j) {
                 const float g0 = rows[0][j] ? rows[0][j][co] : 0.f, g1 = rows[1][j] ? rows[1][j][co] : 0.f,
                             g2 = rows[2][j] ? rows[2][j][co] : 0.f;
                 u[0][j] = g0; u[1][j] = ((g0 + g2) + g1) * 0.5f; u[2][j] = ((g0 + g2) - g1) * 0.5f; u[3][j] = g2;
               }
               for (int nu = 0; nu < 4; ++nu)
-                memcpy(dw + (((size_t)co * nkc + kc) * 12 + nu * 3 + dy) * 16, u[nu], sizeof(u[nu]));
+                memcpy(dw + (((size_t)co * nk8 + kc) * 12 + nu * 3 + dy) * 8, u[nu], sizeof(u[nu]));
             }
           }
       }

@@ -29,7 +29,7 @@ struct ConvParams {
   int nseg;
   int ksize;          // 1, 2, 3; TF 'same': pad_before = (ksize-1)/2, rest after
   const float* w;     // conv_buf_kernel: packed [Cout][ksize*ksize*Ctot] (K contiguous per output channel);
-                      // conv_wino_kernel: [Cout][Ctot/16][12][16] (F(2,3)-transformed along x);
+                      // conv_wino_kernel: [Cout][Ctot/8][12][8] (F(2,3)-transformed along x);
                       // conv_halo_kernel: [Cout][Ctot/16][9][16]; conv_halo_split_kernel: [Cout][Ctot/16][9][3][16] bf16;
                       // conv_igemm_kernel first-layer mode: [48][Cout]
   const float* bias;  // [Cout]
@@ -146,12 +146,12 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                 CONV_TILE_C3 = 32 /* first-layer mode: 3-channel image input, [48][Cout] weights */,
                 CONV_TILE_HALO = 64 /* conv_halo_kernel: shape index = HaloTile, weights [Cout][chunk][tap][16] */,
                 CONV_TILE_WINO = 256 /* conv_wino_kernel (F(2,3) along x): shape index = WinoTile, weights
-                                        [Cout][chunk][nu*3+dy][16] */,
+                                        [Cout][chunk of 8][nu*3+dy][8] */,
                 CONV_TILE_SPLIT = 128 /* conv_halo_split_kernel (precision mode bf16x6): shape index = HaloTile,
                                          weights [Cout][chunk][tap][3 planes][16] bf16 */ };
 // conv_wino_kernel tiles: patch rows x 64 pixels x output channels (waves M x N)
-enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_2x128 = 2 /* 2x2 */, WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */,
-                WINO_SHAPES = 4 };
+enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_4x128_W16 = 2 /* 4x4: 16 waves */,
+                WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */, WINO_4x32 = 4 /* 4x1 */, WINO_SHAPES = 5 };
 // conv_halo_kernel tiles: patch rows x 32 pixels x output channels (waves M x N)
 enum HaloTile { HALO_8x128 = 0 /* 4x2 */, HALO_8x64 = 1 /* 4x1 */, HALO_8x32 = 2 /* 4x1 */, HALO_4x64 = 3 /* 4x1 */,
                 HALO_4x128 = 4 /* 2x2 */, HALO_4x32 = 5 /* 4x1 */, HALO_SHAPES = 6 };

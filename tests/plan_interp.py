@@ -91,8 +91,8 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 if op.get('halo') or op.get('split'):
                     assert ks == 3 and not any(sg['up'] for sg in op['segs'])
             if op.get('ww_off', -1) >= 0:
-                # Winograd copy [Cout][chunk][nu*3+dy][16]: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2
-                ww = packed[op['ww_off']:op['ww_off'] + 12 * ct * co].reshape(co, ct // 16, 4, 3, 16)
+                # Winograd copy [Cout][chunk of 8][nu*3+dy][8]: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2
+                ww = packed[op['ww_off']:op['ww_off'] + 12 * ct * co].reshape(co, ct // 8, 4, 3, 8)
                 ww = ww.transpose(2, 3, 1, 4, 0).reshape(4, 3, ct, co)      # [nu][dy][c][n]
                 g0, g1, g2 = wt[:, 0], wt[:, 1], wt[:, 2]                    # [dy][c][n]
                 half = np.float32(0.5)
