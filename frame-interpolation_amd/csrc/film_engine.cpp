@@ -425,7 +425,8 @@ struct Planner {
     op.split = h->opt_precision == 1 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all);
     // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M
     op.wino = !op.split && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
-              ((L.cout % 128 == 0 && px >= 8192) || px >= 100000 || h->opt_wino == 2);
+              ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
+               px >= 100000 || h->opt_wino == 2);
     if (op.split || op.wino) op.halo = 0;
     op.tile = op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
