@@ -1,27 +1,25 @@
-// conv_igemm.hip -- Conv2D('same', stride 1) + bias + leaky_relu(0.2) as an fp32 implicit GEMM on
-// the gfx950 matrix cores (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise an fmaf chain).
+// conv_igemm.hip -- dispatcher of the convolution kernels: Conv2D('same', stride 1) + bias + leaky_relu(0.2) as
+// implicit GEMMs on the gfx950 matrix cores.
 //
 // Replaces every tf.keras.layers.Conv2D of the reference hot path whose Cout is a multiple of 32:
 //   feature_extractor.py:93-99,142-143   pyramid_flow_estimator.py:66-76,85-98   fusion.py:83-97,135-138
 //
-// Mapping:  M = NB*H*W output pixels (raster order), N = Cout, K = taps x (concatenated input channels).
-//   * one workgroup = 4 waves computes a BM x BN tile; each wave owns a grid of 32x32 MFMA tiles with
-//     their accumulators in registers.
-//   * K is walked in steps of 16 channels of one tap of one concat segment.  The A tile (BM pixels x 16
-//     channels, gathered from NHWC with zero fill outside the image, optional x2 nearest upsample) and
-//     the B tile (16 x BN weights) are staged global -> registers -> LDS, double buffered, one barrier
-//     per step; the global loads of step s+1 are in flight during the MFMAs of step s.
-//   * A rows are stored with a stride of 20 floats so that the ds_read_b128 fragment reads are
-//     bank-conflict free (MI355X_MICROARCH.md, LDS table: rows distinct mod 16 per 16-lane group).
-//   * the epilogue adds the bias, applies leaky_relu and stores 128-byte rows into the channel slice
-//     of the destination buffer (the consumer's concat input).
-// Kernel templates (the family of a layer is a pure function of its shape and the precision option):
-//   conv_wino_impl.h   3x3 convs with Cout % 128 == 0 on the large levels: 1-D Winograd F(2,3) along x on the halo
-//                      staging, 1.5x fewer fp32 MFMAs.
+// Common mapping: M = output pixels, N = Cout, K = taps x (concatenated input channels); 4, 8 or 16 waves per
+// workgroup, each wave owning a grid of 32x32 MFMA tiles with their accumulators in registers; inputs gathered from
+// channel slices of NHWC buffers with 32-bit buffer offsets (zero padding = the bounds check), the epilogue adds the
+// bias, applies leaky_relu and stores 128-byte rows into the channel slice of the destination buffer (the consumer's
+// concat input).  fp32 throughout (v_mfma_f32_32x32x2_f32) except the opt-in bf16x6 mode.
+//
+// Kernel templates (the family of a layer is a pure function of its shape and the engine options, never of timing):
+//   conv_wino_impl.h   3x3 convs on the large levels: 1-D Winograd F(2,3) along x on the halo staging, 1.5x fewer
+//                      fp32 MFMAs.
 //   conv_halo_impl.h   3x3 convs with deep K: the activation halo patch is staged once per 16-channel chunk and the
 //                      nine taps run out of LDS (6.8x fewer A loads / LDS stores, less L2 traffic, higher clocks).
-//   conv_buf_impl.h    the general kernel: buffer loads with hardware zero fill, K-major weights, no vector
-//                      instruction per K-step besides loads, LDS traffic and MFMAs.
+//   conv_split_impl.h  precision mode bf16x6: the halo kernel with every fp32 operand split exactly into three bf16
+//                      pieces, six partial products on the bf16 matrix pipe.
+//   conv_buf_impl.h    the general kernel (1x1, small levels, and the sub-pixel-folded upsample + 2x2 convs): buffer
+//                      loads with hardware zero fill, K-major weights, no vector instruction per K-step besides loads,
+//                      LDS traffic and MFMAs.
 //   conv_igemm_impl.h  the first-generation kernel (64-bit pointers, select-based zero fill, [K][N] weights);
 //                      still runs the 3-channel first layer (its 4-taps-per-step mode) and is the A/B baseline
 //                      of tools/conv_bench.hip.
