@@ -362,11 +362,13 @@ hipError_t conv_igemm_launch(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(BM * (BKC + 4) + BKC * BN) * sizeof(float);
   auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BKC, FLAGS>;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
   dim3 grid((p.M + BM - 1) / BM, p.Cout / BN);

@@ -274,11 +274,13 @@ hipError_t conv_wino16_launch(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (2 * (size_t)(TH + 2) * 4 * 32 * 16 + 2 * 3 * (size_t)BN * 16) * sizeof(float);
   auto kern = conv_wino16_kernel<TH, BN, WGM, WGN, FLAGS>;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
   const int ntx = (p.W + 63) / 64, nty = (p.H + TH - 1) / TH;
