@@ -88,6 +88,9 @@ static hipError_t launch_wino(const ConvParams& p, int shape, hipStream_t s) {
     case WINO_4x64: return conv_wino_launch<4, 64, 4, 1, F>(p, s);
     case WINO_4x128_W16: return conv_wino_launch<4, 128, 4, 4, F>(p, s);
     case WINO_4x32: return conv_wino_launch<4, 32, 4, 1, F>(p, s);
+    case WINO_8x64_W16: return conv_wino_launch<8, 64, 8, 2, F>(p, s);
+    case WINO_8x32_W8: return conv_wino_launch<8, 32, 8, 1, F>(p, s);
+    case WINO_2x64: return conv_wino_launch<2, 64, 2, 2, F>(p, s);
     case WINO_4x64_W8: return conv_wino_launch<4, 64, 4, 2, F>(p, s);
     default: return hipErrorInvalidValue;
   }

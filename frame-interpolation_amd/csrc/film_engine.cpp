@@ -793,9 +793,9 @@ std::vector<int> halo_candidates(int Cout) {
 }
 
 std::vector<int> wino_candidates(int Cout) {
-  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_4x128_W16, WINO_4x128, WINO_4x64}
-                            : Cout % 64 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_4x64, WINO_4x32}
-                                             : std::vector<int>{WINO_4x32};
+  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_8x64_W16, WINO_2x64, WINO_4x128_W16, WINO_4x128}
+                            : Cout % 64 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_8x64_W16, WINO_2x64, WINO_4x32}
+                                             : std::vector<int>{WINO_4x32, WINO_8x32_W8};
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_XCD); }
   return out;

@@ -151,7 +151,8 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                                          weights [Cout][chunk][tap][3 planes][16] bf16 */ };
 // conv_wino_kernel tiles: patch rows x 64 pixels x output channels (waves M x N)
 enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_4x128_W16 = 2 /* 4x4: 16 waves */,
-                WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */, WINO_4x32 = 4 /* 4x1 */, WINO_SHAPES = 5 };
+                WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */, WINO_4x32 = 4 /* 4x1 */, WINO_8x64_W16 = 5 /* 8x2 */,
+                WINO_8x32_W8 = 6 /* 8x1 */, WINO_2x64 = 7 /* 2x2 */, WINO_SHAPES = 8 };
 // conv_halo_kernel tiles: patch rows x 32 pixels x output channels (waves M x N)
 enum HaloTile { HALO_8x128 = 0 /* 4x2 */, HALO_8x64 = 1 /* 4x1 */, HALO_8x32 = 2 /* 4x1 */, HALO_4x64 = 3 /* 4x1 */,
                 HALO_4x128 = 4 /* 2x2 */, HALO_4x32 = 5 /* 4x1 */, HALO_SHAPES = 6 };
