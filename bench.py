@@ -113,9 +113,9 @@ def main():
     ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--precision', type=int, default=0, choices=[0, 1],
-                    help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6')
-    ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 precision-mode measurement')
+    ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
+                    help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
+    ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
     ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
     args = ap.parse_args()
 
@@ -259,7 +259,7 @@ def main():
             'metric': 'interpolated frames/sec @1080p', 'value': round(value, 4), 'unit': 'frames/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32' if not args.precision else 'f32 via bf16x6 exact-split MFMA (opt-in mode)',
+            'vs_baseline': None, 'dtype': 'f32' if not args.precision else ('f32 via bf16x6 exact-split MFMA (opt-in mode)' if args.precision == 1 else 'bf16x3 split MFMA, f32 accumulate (opt-in mode)'),
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {Wd}x{H} pair, align {align}, block_shape {block} -> '
                                    f'{ntiles} tile(s) of {tile_hw[1]}x{tile_hw[0]} in one batch, film_net published '
@@ -274,20 +274,23 @@ def main():
             # operand, six partial products, fp32 accumulate) on the same workload, with its distance from the
             # default fp32-MFMA result.
             ref_out = out.clone()
-            eng.set_option('precision', 1)
-            for _ in range(max(1, args.warmup)):
-                out2 = it(x0, x1)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                out2 = it(x0, x1)
-            torch.cuda.synchronize()
-            dt2 = time.perf_counter() - t1
-            result['precision_mode_bf16x6'] = {
-                'value': round(args.steps / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
-                'max_abs_diff_vs_f32_mode': float((out2 - ref_out).abs().max()),
-                'note': 'opt-in (film_set_option precision=1); the headline value above is the fp32-MFMA default',
-            }
+            for mode, name, what in ((1, 'bf16x6', 'exact 3-way bf16 split, six partial products'),
+                                     (2, 'bf16x3', '2-way nearest bf16 split, three partial products')):
+                eng.set_option('precision', mode)
+                for _ in range(max(1, args.warmup)):
+                    out2 = it(x0, x1)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    out2 = it(x0, x1)
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+                result['precision_mode_' + name] = {
+                    'value': round(args.steps / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                    'max_abs_diff_vs_f32_mode': float((out2 - ref_out).abs().max()),
+                    'note': f'opt-in (film_set_option precision={mode}: {what}, fp32 accumulate); '
+                            'the headline value above is the fp32-MFMA default',
+                }
             eng.set_option('precision', 0)
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(weights)

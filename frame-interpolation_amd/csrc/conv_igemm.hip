@@ -68,15 +68,15 @@ static hipError_t launch_halo(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
-template <int F>
+template <int F, int NP>
 static hipError_t launch_split(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
-    case HALO_8x128: return conv_halo_split_launch<8, 128, 4, 2, 6, F>(p, s);
-    case HALO_8x64: return conv_halo_split_launch<8, 64, 4, 1, 6, F>(p, s);
-    case HALO_8x32: return conv_halo_split_launch<8, 32, 4, 1, 6, F>(p, s);
-    case HALO_4x64: return conv_halo_split_launch<4, 64, 4, 1, 6, F>(p, s);
-    case HALO_4x128: return conv_halo_split_launch<4, 128, 2, 2, 6, F>(p, s);
-    case HALO_4x32: return conv_halo_split_launch<4, 32, 4, 1, 6, F>(p, s);
+    case HALO_8x128: return conv_halo_split_launch<8, 128, 4, 2, NP, F>(p, s);
+    case HALO_8x64: return conv_halo_split_launch<8, 64, 4, 1, NP, F>(p, s);
+    case HALO_8x32: return conv_halo_split_launch<8, 32, 4, 1, NP, F>(p, s);
+    case HALO_4x64: return conv_halo_split_launch<4, 64, 4, 1, NP, F>(p, s);
+    case HALO_4x128: return conv_halo_split_launch<4, 128, 2, 2, NP, F>(p, s);
+    case HALO_4x32: return conv_halo_split_launch<4, 32, 4, 1, NP, F>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -106,7 +106,8 @@ hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   }
   if (tile & CONV_TILE_SPLIT) {
     if (p.ksize != 3) return hipErrorInvalidValue;
-    return (tile & CONV_TILE_XCD) ? launch_split<CONV_B_XCD_M>(p, shape, s) : launch_split<0>(p, shape, s);
+    if (tile & CONV_TILE_X3) return (tile & CONV_TILE_XCD) ? launch_split<CONV_B_XCD_M, 3>(p, shape, s) : launch_split<0, 3>(p, shape, s);
+    return (tile & CONV_TILE_XCD) ? launch_split<CONV_B_XCD_M, 6>(p, shape, s) : launch_split<0, 6>(p, shape, s);
   }
   if (tile & CONV_TILE_HALO) {
     if (p.ksize != 3) return hipErrorInvalidValue;

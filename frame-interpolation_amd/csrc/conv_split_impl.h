@@ -1,17 +1,20 @@
-// conv_split_impl.h -- OPT-IN precision mode "bf16x6" (film_set_option("precision", 1); the default engine path is
-// the fp32 MFMA of conv_halo_impl.h / conv_buf_impl.h): the halo-staged 3x3 convolution with every fp32
-// operand split EXACTLY into three bf16 pieces (x = hi + mid + lo: 8 + 8 + 8 significant bits, by truncation) and
-// the product formed from the six partial products of weight >= 2^-16,
-//     a*b ~= hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)        (dropped: mid*lo, lo*mid, lo*lo <= 2^-24),
-// on v_mfma_f32_32x32x16_bf16 (fp32 accumulate; bf16 x bf16 products are exact in fp32).  Six bf16 MFMAs of 32
-// cycles replace eight fp32 MFMAs of 64 cycles per 16 K: 2.67x the matrix rate at fp32-level accuracy (measured
-// against the fp32 kernels on the same data, tools/conv_bench.hip: max |delta| 2.8e-5 on outputs of O(10), the same
-// as between two fp32 kernels that sum K in a different order).  Measured speed: 1.45-1.65x - at 68 % MFMA-pipe
-// occupancy the bf16 matrix pipe is power limited (clock 1.9 GHz), like every dense bf16 GEMM on this part.
+// conv_split_impl.h -- OPT-IN precision modes "bf16x6" / "bf16x3" (film_set_option("precision", 1 / 2); the default
+// engine path is the fp32 MFMA of conv_wino_impl.h / conv_halo_impl.h / conv_buf_impl.h): the halo-staged 3x3
+// convolution with every fp32 operand split into bf16 pieces x = hi + mid + lo (round-to-nearest-even pieces,
+// 8 + 8 + 8 significant bits, the sum is EXACT - see conv_split4) and the product formed on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate; bf16 x bf16 products are exact in fp32) from
+//   NPROD = 6:  hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)     dropped: mid*lo, lo*mid, lo*lo <= 2^-25 |ab|
+//   NPROD = 3:  hi*hi + (hi*mid + mid*hi)                                  dropped terms <= 3 * 2^-18 |ab|, zero mean
+// Six (three) bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16 K: 2.67x (5.3x) the matrix
+// rate.  bf16x6 is fp32-level accurate (max |delta| 2.8e-5 on outputs of O(10) against the fp32 kernels,
+// tools/conv_bench.hip: the same as between two fp32 kernels that sum K in a different order); bf16x3 stages only
+// the hi and mid planes (2/3 of the LDS and of the split VALU work).  Measured speed of bf16x6: 1.45-1.65x - at
+// 68 % MFMA-pipe occupancy the bf16 matrix pipe is power limited (clock 1.9 GHz), like every dense bf16 GEMM on
+// this part.
 //
 //   * activations stay fp32 in HBM; the split happens once per staged element on the way into LDS (the halo
 //     staging amortises it over the nine taps); weights are split once on the host side:
-//     [Cout][chunk][tap][plane][16] bf16.
+//     [Cout][chunk][tap][plane][16] bf16 (bf16x3 reads planes 0 and 1 of the same copy).
 //   * LDS image, plane major: [plane][row][16 bf16 = 32 B]; the two 16-byte K-halves of row r are swapped when bit 3 of
 //     r is set.  Reads: the 16 rows of a ds_read_b128 lane group then hit 16 distinct bank quads (rows r and r+8 /
 //     r+24 would collide otherwise); writes: 4 rows x 32 contiguous bytes per 16-lane ds_write_b64 group.  (The first
@@ -27,23 +30,31 @@ __device__ __forceinline__ su4 conv_buf_load_u4(conv_rsrc_t rsrc, unsigned voff,
   return __builtin_bit_cast(su4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
 }
 
-// exact 3-way split of four floats into bf16 planes (each plane: 4 bf16 = 2 dwords)
+typedef __bf16 sbf2 __attribute__((ext_vector_type(2)));
+typedef float sf2 __attribute__((ext_vector_type(2)));
+
+// Round-to-nearest-even split of four floats into bf16 planes (each plane: 4 bf16 = 2 dwords; channel i in the low
+// half of dword i/2): hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  Both differences are exact in
+// fp32 and the last one fits 8 significant bits, so hi + mid + lo == x EXACTLY (|x - hi| <= 2^-9 |x| is a multiple of
+// ulp(x) -> 16 bits; |x - hi - mid| <= 2^-17 |x| -> 8 bits).  Rounding (v_cvt_pk_bf16_f32) instead of truncation keeps
+// the pieces' signs uncorrelated with x, which is what makes the 2-plane "bf16x3" mode unbiased.
+template <bool WITH_LO>
 __device__ __forceinline__ void conv_split4(bf4 x, su2& hi, su2& mid, su2& lo) {
-  unsigned h[4], m[4], l[4];
+  unsigned hp[2], mp[2], lp[2] = {0u, 0u};
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned xb = __float_as_uint(x[i]);
-    const unsigned hb = xb & 0xFFFF0000u;
-    const float r = x[i] - __uint_as_float(hb);
-    const unsigned rb = __float_as_uint(r);
-    const unsigned mb = rb & 0xFFFF0000u;
-    const float q = r - __uint_as_float(mb);
-    h[i] = hb; m[i] = mb; l[i] = __float_as_uint(q);
+  for (int j = 0; j < 2; ++j) {
+    const sf2 v = {x[2 * j], x[2 * j + 1]};
+    hp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sbf2));
+    const sf2 r = {v.x - __uint_as_float(hp[j] << 16), v.y - __uint_as_float(hp[j] & 0xFFFF0000u)};
+    mp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sbf2));
+    if constexpr (WITH_LO) {
+      const sf2 q = {r.x - __uint_as_float(mp[j] << 16), r.y - __uint_as_float(mp[j] & 0xFFFF0000u)};
+      lp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, sbf2));
+    }
   }
-  // pack the upper halves of two floats into one dword (bytes 3,2 of the second | bytes 3,2 of the first)
-  hi.x = __builtin_amdgcn_perm(h[1], h[0], 0x07060302u); hi.y = __builtin_amdgcn_perm(h[3], h[2], 0x07060302u);
-  mid.x = __builtin_amdgcn_perm(m[1], m[0], 0x07060302u); mid.y = __builtin_amdgcn_perm(m[3], m[2], 0x07060302u);
-  lo.x = __builtin_amdgcn_perm(l[1], l[0], 0x07060302u); lo.y = __builtin_amdgcn_perm(l[3], l[2], 0x07060302u);
+  hi.x = hp[0]; hi.y = hp[1];
+  mid.x = mp[0]; mid.y = mp[1];
+  lo.x = lp[0]; lo.y = lp[1];
 }
 
 template <int TH, int BN, int WGM, int WGN, int NPROD, int FLAGS>
@@ -54,13 +65,15 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
   constexpr int HR = TH + 2, HC = 34;
   constexpr int A_PLANE = HR * HC * 32;          // bytes: one bf16 plane of the halo chunk
   constexpr int B_PLANE = BN * 32;
-  constexpr int A_STAGE = 3 * A_PLANE;           // bytes
-  constexpr int B_STAGE = 3 * B_PLANE;
+  constexpr int NPL = NPROD > 3 ? 3 : 2;         // planes staged: bf16x3 (hi*hi + hi*mid + mid*hi) never reads lo
+  constexpr int A_STAGE = NPL * A_PLANE;         // bytes
+  constexpr int B_STAGE = NPL * B_PLANE;
   constexpr int HF4 = HR * HC * 4;
   constexpr int AH = (HF4 + NT - 1) / NT;
-  constexpr int BU = BN * 6;                     // 16-byte units of one weight step
+  constexpr int BU = BN * 2 * NPL;               // 16-byte units of one weight step
   constexpr int BLD = (BU + NT - 1) / NT;
   static_assert(TH % WGM == 0 && TM >= 1 && TN >= 1, "bad tile");
+  static_assert(NPROD == 6 || NPROD == 3, "bf16x6 or bf16x3");
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem_b[];  // [A0][A1][B x3]
@@ -156,10 +169,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
     for (int i = 0; i < AH; ++i) {
       if (NT * (i + 1) <= HF4 || alds[i] >= 0) {
         su2 hi, mid, lo;
-        conv_split4(areg[i], hi, mid, lo);
+        conv_split4<NPL == 3>(areg[i], hi, mid, lo);
         *reinterpret_cast<su2*>(As + alds[i]) = hi;
         *reinterpret_cast<su2*>(As + alds[i] + A_PLANE) = mid;
-        *reinterpret_cast<su2*>(As + alds[i] + 2 * A_PLANE) = lo;
+        if constexpr (NPL == 3) *reinterpret_cast<su2*>(As + alds[i] + 2 * A_PLANE) = lo;
       }
     }
   };
@@ -206,9 +219,9 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
   auto compute = [&](auto tap_c) {
     constexpr int TAP = decltype(tap_c)::value;
     constexpr int DY = TAP / 3, DX = TAP % 3;
-    sbf8 a[3][TM], b[3][TN];
+    sbf8 a[NPL][TM], b[NPL][TN];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
+    for (int pl = 0; pl < NPL; ++pl) {
 #pragma unroll
       for (int mt = 0; mt < TM; ++mt)
         a[pl][mt] = __builtin_bit_cast(sbf8, smem16[a_ad[mt + DY][DX] + a_stage_u + pl * (A_PLANE / 16)]);
@@ -289,7 +302,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_halo_split_kernel(ConvPara
 
 template <int TH, int BN, int WGM, int WGN, int NPROD, int FLAGS>
 hipError_t conv_halo_split_launch(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = 2 * 3 * (size_t)(TH + 2) * 34 * 32 + 3 * 3 * (size_t)BN * 32;
+  constexpr size_t npl = NPROD > 3 ? 3 : 2;
+  constexpr size_t lds = 2 * npl * (size_t)(TH + 2) * 34 * 32 + 3 * npl * (size_t)BN * 32;
   auto kern = conv_halo_split_kernel<TH, BN, WGM, WGN, NPROD, FLAGS>;
   if constexpr (lds > 64 * 1024) {
     static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device

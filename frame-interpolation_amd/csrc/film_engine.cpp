@@ -158,7 +158,7 @@ struct film_handle {
   int opt_tune_ms = 0;    // autotune: minimum kernel time spent per candidate (0: two launches)
   int opt_lanes = 1;      // 1: replay graphs use a second (side) stream for independent small / HBM-bound work
   hipStream_t stream2 = nullptr;
-  int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs
+  int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs; 2: bf16x3
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
 };
@@ -422,14 +422,15 @@ struct Planner {
       op.halo = L.has_halo() && !any_up && px >= 8192 &&
                 (ctot >= 768 || (ctot >= 512 && px >= 100000) || L.cout == 32);
     // precision mode bf16x6: every 3x3 conv that is large enough to be matrix-pipe bound
-    op.split = h->opt_precision == 1 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all);
+    // (op.split: 1 = bf16x6, 2 = bf16x3 - same kernel, two planes and three products)
+    op.split = (h->opt_precision != 0 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all)) ? h->opt_precision : 0;
     // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M
     op.wino = !op.split && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
               ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
                px >= 100000 || h->opt_wino == 2);
     if (op.split || op.wino) op.halo = 0;
     op.tile = op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
-              : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | CONV_TILE_XCD)
+              : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
@@ -792,6 +793,20 @@ std::vector<int> halo_candidates(int Cout) {
   return out;
 }
 
+// float -> bfloat16, round to nearest even (what v_cvt_pk_bf16_f32 does; weights are finite)
+static inline uint16_t bf16_rne(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_float(uint16_t b) {
+  const uint32_t u = (uint32_t)b << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
 std::vector<int> wino_candidates(int Cout) {
   std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_8x64_W16, WINO_2x64, WINO_4x128_W16, WINO_4x128}
                             : Cout % 64 == 0 ? std::vector<int>{WINO_4x64_W8, WINO_8x64_W16, WINO_2x64, WINO_4x32}
@@ -801,9 +816,9 @@ std::vector<int> wino_candidates(int Cout) {
   return out;
 }
 
-std::vector<int> split_candidates(int Cout) {
+std::vector<int> split_candidates(int Cout, bool x3) {
   std::vector<int> out;
-  for (int t : halo_candidates(Cout)) out.push_back((t & ~CONV_TILE_HALO) | CONV_TILE_SPLIT);
+  for (int t : halo_candidates(Cout)) out.push_back((t & ~CONV_TILE_HALO) | CONV_TILE_SPLIT | (x3 ? CONV_TILE_X3 : 0));
   return out;
 }
 
@@ -845,7 +860,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -1164,20 +1179,14 @@ int film_finalize(film_t* h) {
             for (int j = 0; j < 16; ++j) v[j] = rows[j] ? rows[j][co] : 0.f;
             memcpy(dst + (size_t)co * ktot + (size_t)tap * ct + kc * 16, v, sizeof(v));
             if (dh) memcpy(dh + (((size_t)co * nkc + kc) * 9 + tap) * 16, v, sizeof(v));
-            if (ds) {  // exact 3-way bf16 split by truncation: 8 + 8 + 8 significant bits
+            if (ds) {  // exact 3-way bf16 split, round-to-nearest-even pieces (same as conv_split4 on the device)
               uint16_t* d = ds + (((size_t)co * nkc + kc) * 9 + tap) * 48;
               for (int j = 0; j < 16; ++j) {
-                uint32_t xb, hb, rb, mb, qb;
-                memcpy(&xb, &v[j], 4);
-                hb = xb & 0xFFFF0000u;
-                float hf; memcpy(&hf, &hb, 4);
-                const float r = v[j] - hf;
-                memcpy(&rb, &r, 4);
-                mb = rb & 0xFFFF0000u;
-                float mf; memcpy(&mf, &mb, 4);
-                const float q = r - mf;
-                memcpy(&qb, &q, 4);
-                d[j] = (uint16_t)(hb >> 16); d[16 + j] = (uint16_t)(mb >> 16); d[32 + j] = (uint16_t)(qb >> 16);
+                const uint16_t hb = bf16_rne(v[j]);
+                const float r = v[j] - bf16_to_float(hb);
+                const uint16_t mb = bf16_rne(r);
+                const float q = r - bf16_to_float(mb);
+                d[j] = hb; d[16 + j] = mb; d[32 + j] = bf16_rne(q);
               }
             }
           }
@@ -1324,7 +1333,7 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "precision")) {
-    if (value != 0 && value != 1) return fail(h, FILM_ERR_INVALID, "precision: 0 (f32) or 1 (bf16x6)");
+    if (value != 0 && value != 1 && value != 2) return fail(h, FILM_ERR_INVALID, "precision: 0 (f32), 1 (bf16x6) or 2 (bf16x3)");
     if ((int)value != h->opt_precision) {  // plans carry the kernel choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());

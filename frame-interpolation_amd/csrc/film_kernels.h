@@ -148,7 +148,8 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                 CONV_TILE_WINO = 256 /* conv_wino_kernel (F(2,3) along x): shape index = WinoTile, weights
                                         [Cout][chunk of 8][nu*3+dy][8] */,
                 CONV_TILE_SPLIT = 128 /* conv_halo_split_kernel (precision mode bf16x6): shape index = HaloTile,
-                                         weights [Cout][chunk][tap][3 planes][16] bf16 */ };
+                                         weights [Cout][chunk][tap][3 planes][16] bf16 */,
+                CONV_TILE_X3 = 512 /* with CONV_TILE_SPLIT: precision mode bf16x3 - planes hi, mid only, three products */ };
 // conv_wino_kernel tiles: patch rows x 64 pixels x output channels (waves M x N)
 enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_4x128_W16 = 2 /* 4x4: 16 waves */,
                 WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */, WINO_4x32 = 4 /* 4x1 */, WINO_8x64_W16 = 5 /* 8x2 */,

@@ -105,6 +105,9 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 planes = (raw.astype(np.uint32) << 16).view(np.float32).reshape(co, ct // 16, 3, 3, 3, 16)
                 ws = planes.astype(np.float64).sum(axis=4).transpose(2, 3, 1, 4, 0).reshape(3, 3, ct, co)
                 assert np.array_equal(ws.astype(np.float32), wt) and np.array_equal(ws, wt.astype(np.float64)), 'bf16x6 split is not exact'
+                # round-to-nearest pieces: the two planes bf16x3 uses are within 2^-17 of the weight
+                two = planes.astype(np.float64)[:, :, :, :, :2].sum(axis=4).transpose(2, 3, 1, 4, 0).reshape(3, 3, ct, co)
+                assert np.all(np.abs(two - wt) <= np.abs(wt.astype(np.float64)) * 2.0 ** -17), 'hi + mid is not a nearest split'
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             _view(arena, op['out'], nb, h, w)[...] = y

@@ -257,10 +257,33 @@ def test_precision_bf16x6_mode(published):
     e2.close()
 
 
-@pytest.mark.parametrize('precision', [0, 1])
+def test_precision_bf16x3_mode(published):
+    """Opt-in precision mode 2 (nearest 2-way bf16 split, hi*hi + hi*mid + mid*hi, fp32 accumulate): per product
+    the dropped terms are <= 3 * 2^-18 relative with zero mean, so the result stays well inside the north_star
+    bound against the oracle - measured here and printed, asserted with a 4x margin."""
+    from film_hip.engine import FilmEngine
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    x0, x1 = _pair(1, 128, 192, seed=43)
+    ref = eng.forward(x0, x1)
+    want = fo.film_forward(x0, x1, w, fo.Options())
+    e2 = FilmEngine(opt, device=0)
+    e2.set_weights(w)
+    e2.set_option('precision', 2)
+    plan = e2.plan(1, 128, 192)
+    assert sum(1 for op in plan['ops'] if op.get('split') == 2) >= 10
+    got = e2.forward(x0, x1)
+    err_oracle, err_f32 = np.abs(got - want).max(), np.abs(got - ref).max()
+    print(f'bf16x3 vs oracle {err_oracle:.2e}, vs f32 engine {err_f32:.2e}; f32 engine vs oracle {np.abs(ref - want).max():.2e}')
+    assert err_oracle < IMAGE_TOL / 4
+    assert np.array_equal(got, e2.forward(x0, x1))
+    e2.close()
+
+
+@pytest.mark.parametrize('precision', [0, 1, 2])
 @pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192)])
 def test_halo_kernels_on_every_level(published, precision, b, h, w):
-    """halo_all = 1 forces conv_halo_kernel (precision 0) / conv_halo_split_kernel (precision 1) onto every 3x3
+    """halo_all = 1 forces conv_halo_kernel (precision 0) / conv_halo_split_kernel (precision 1, 2) onto every 3x3
     convolution, i.e. onto ragged patches down to 1 x 1 pixels (W < 32, H not a multiple of the patch height),
     multi-segment inputs and batch remaps: stage-by-stage parity with the oracle."""
     from film_hip.engine import FilmEngine
@@ -273,7 +296,7 @@ def test_halo_kernels_on_every_level(published, precision, b, h, w):
     plan = eng.plan(b, h, w)
     key = 'split' if precision else 'halo'
     n3 = sum(1 for op in plan['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 3 and not op['c3'])
-    assert sum(op[key] for op in plan['ops']) == n3 > 40
+    assert sum(1 for op in plan['ops'] if op.get(key)) == n3 > 40
     x0, x1 = _pair(b, h, w, seed=47 + h + w)
     _check_stages(eng, opt, wts, x0, x1)
     eng.close()

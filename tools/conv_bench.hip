@@ -88,19 +88,20 @@ __global__ void pack_halo_kernel(const float* src, float* dst, int C, int N) {
   dst[(((size_t)n * (C / 16) + c / 16) * 9 + tap) * 16 + c % 16] = src[i];
 }
 
-// [tap*C + c][N] fp32 -> [N][chunk][tap][plane][16] bf16, exact 3-way truncation split
+// [tap*C + c][N] fp32 -> [N][chunk][tap][plane][16] bf16, exact 3-way round-to-nearest split
 __global__ void pack_split_kernel(const float* src, unsigned short* dst, int C, int N) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)9 * C * N) return;
   const int k = (int)(i / N), n = (int)(i % N);
   const int tap = k / C, c = k % C;
   const float x = src[i];
-  const unsigned hb = __float_as_uint(x) & 0xFFFF0000u;
+  auto rne = [](float v) { unsigned u = __float_as_uint(v); u += 0x7FFFu + ((u >> 16) & 1u); return u & 0xFFFF0000u; };
+  const unsigned hb = rne(x);
   const float r = x - __uint_as_float(hb);
-  const unsigned mb = __float_as_uint(r) & 0xFFFF0000u;
+  const unsigned mb = rne(r);
   const float q = r - __uint_as_float(mb);
   unsigned short* d = dst + ((((size_t)n * (C / 16) + c / 16) * 9 + tap) * 3) * 16 + c % 16;
-  d[0] = (unsigned short)(hb >> 16); d[16] = (unsigned short)(mb >> 16); d[32] = (unsigned short)(__float_as_uint(q) >> 16);
+  d[0] = (unsigned short)(hb >> 16); d[16] = (unsigned short)(mb >> 16); d[32] = (unsigned short)(rne(q) >> 16);
 }
 
 // [tap*C + c][N] -> [N][chunk][nu*3 + dy][16]: F(2,3) weight transform along x
