@@ -71,7 +71,8 @@ struct OpDesc {
   int ftaps = 0; int tdy[4] = {0, 0, 0, 0}, tdx[4] = {0, 0, 0, 0};
   int64_t fold_woff[4] = {0, 0, 0, 0};  // fold == 2: weight offset of phase q relative to w_off
   int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
-  int wino = 0;                       // conv: runs on conv_wino_kernel
+  int64_t wx_off = -1;                // conv: ... and its 2-plane bf16 split (precision mode bf16x3, conv_winox3_kernel)
+  int wino = 0;                       // conv: 1 = runs on conv_wino_kernel, 2 = on conv_winox3_kernel (precision bf16x3)
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
   int lane = 0;                       // graph replay: 0 = main stream, 1 = side stream (small / HBM-bound work)
   std::vector<int> xdeps;             // ops on the OTHER lane this op must wait for (from the buffer overlap analysis)
@@ -99,6 +100,8 @@ struct LayerPack {
   int64_t wf_off = -1;       // 2x2 layers behind a nearest upsample: the four sub-pixel phases, pre-summed weights,
                              //     phase (py,px) at wf_off + fold_phase_off(py,px): [Cout][ntaps_p * ctot], 9*ctot*cout in all
   int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/8][12][8]
+  int64_t wx_off = -1;       // ... and the transformed copy split into bf16 hi / mid for conv_winox3_kernel,
+                             //     [Cout][ctot/16][dy][j][h][plane][16] bf16 (nu = 2h + j)
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
                              //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
@@ -311,6 +314,8 @@ void build_layers(film_t* h) {
       L.ws_off = off; off += (L.packed_rows() * L.cout * 3 + 1) / 2;
       off = (off + 3) & ~int64_t(3);
       L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12;
+      off = (off + 3) & ~int64_t(3);
+      L.wx_off = off; off += L.packed_rows() * L.cout / 9 * 12;
     }
     off = (off + 3) & ~int64_t(3);
   }
@@ -384,7 +389,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off;
     if (h->opt_fold && L.wf_off >= 0 && op.nseg == 1 && segs[0].up && !(H & 1) && !(W & 1)) {
       // nearest x2 + 2x2 'same' conv == four phase convolutions on the low-resolution input: kernel tap (dy, dx) of
       // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
@@ -424,12 +429,23 @@ struct Planner {
     // precision mode bf16x6: every 3x3 conv that is large enough to be matrix-pipe bound
     // (op.split: 1 = bf16x6, 2 = bf16x3 - same kernel, two planes and three products)
     op.split = (h->opt_precision != 0 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all)) ? h->opt_precision : 0;
-    // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M
-    op.wino = !op.split && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
+    // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M.
+    // In precision mode bf16x3 the same layers run the Winograd form of the split kernel (conv_winox3_kernel).
+    op.wino = op.split != 1 && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
               ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
                px >= 100000 || h->opt_wino == 2);
+    if (op.wino && h->opt_precision == 2 && (op.split == 2 || h->opt_wino == 2)) {
+      // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  Standalone (tools/conv_bench.hip) the Winograd form
+      // wins on the deep 128-channel-tile layers (427 vs 367 TFLOP/s at K = 22 032) and loses on 64 -> 64 at full
+      // resolution (250 vs 312); in the whole 1080p step taking every Cout % 64 == 0 layer measured best
+      // (34.4 ms vs 34.9 ms with Cout % 128 == 0 only vs 35.3 ms without the kernel).  FILM_WX3_MINCOUT: tuning knob.
+      static const int min_cout = getenv("FILM_WX3_MINCOUT") ? atoi(getenv("FILM_WX3_MINCOUT")) : 64;
+      if (L.cout % 128 == 0 || (L.cout >= min_cout && L.cout % 64 == 0) || min_cout <= 32 || h->opt_wino == 2) op.split = 0, op.wino = 2;
+      else if (op.split == 2) op.wino = 0;
+    }
     if (op.split || op.wino) op.halo = 0;
-    op.tile = op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
+    op.tile = op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
+              : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
@@ -724,7 +740,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
       p.ksize = op.ksize;
-      p.w = wts + ((op.tile & CONV_TILE_WINO) ? op.ww_off : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
+      p.w = wts + ((op.tile & CONV_TILE_WINO) ? ((op.tile & CONV_TILE_X3) ? op.wx_off : op.ww_off) : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
                    : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
       p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
@@ -816,6 +832,15 @@ std::vector<int> wino_candidates(int Cout) {
   return out;
 }
 
+std::vector<int> winox3_candidates(int Cout) {
+  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WX3_4x128_T22, WX3_4x64_T12, WX3_4x64_T21}
+                            : Cout % 64 == 0 ? std::vector<int>{WX3_4x64_T12, WX3_4x64_T21, WX3_4x32_T11}
+                                             : std::vector<int>{WX3_4x32_T11};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_X3); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> split_candidates(int Cout, bool x3) {
   std::vector<int> out;
   for (int t : halo_candidates(Cout)) out.push_back((t & ~CONV_TILE_HALO) | CONV_TILE_SPLIT | (x3 ? CONV_TILE_X3 : 0));
@@ -860,7 +885,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -978,7 +1003,7 @@ std::string plan_json(film_t* h, const Plan& P) {
   for (size_t i = 0; i < h->layers.size(); ++i) {
     const LayerPack& L = h->layers[i];
     o << (i ? "," : "") << "{\"name\":\"" << L.name << "\",\"kh\":" << L.kh << ",\"kw\":" << L.kw << ",\"cin\":" << L.cin
-      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << ",\"ws_off\":" << L.ws_off << ",\"ww_off\":" << L.ww_off << "}";
+      << ",\"cout\":" << L.cout << ",\"ctot\":" << L.ctot() << ",\"w_off\":" << L.w_off << ",\"b_off\":" << L.b_off << ",\"wh_off\":" << L.wh_off << ",\"ws_off\":" << L.ws_off << ",\"ww_off\":" << L.ww_off << ",\"wx_off\":" << L.wx_off << "}";
   }
   o << "],\"ops\":[";
   for (size_t i = 0; i < P.ops.size(); ++i) {
@@ -986,7 +1011,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
@@ -1217,7 +1242,8 @@ int film_finalize(film_t* h) {
       if (L.ww_off >= 0) {  // F(2,3) along x: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2 per (dy, cin, cout);
                             // 8-channel chunks: [Cout][chunk8][nu*3+dy][8]
         float* dw = h->packed_host.data() + L.ww_off;
-        const size_t nk8 = (size_t)ct / 8;
+        uint16_t* dx3 = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.wx_off);
+        const size_t nk8 = (size_t)ct / 8, nk16 = (size_t)ct / 16;
         for (int dy = 0; dy < 3; ++dy)
           for (size_t kc = 0; kc < nk8; ++kc) {
             const float* rows[3][8];
@@ -1233,8 +1259,16 @@ int film_finalize(film_t* h) {
                             g2 = rows[2][j] ? rows[2][j][co] : 0.f;
                 u[0][j] = g0; u[1][j] = ((g0 + g2) + g1) * 0.5f; u[2][j] = ((g0 + g2) - g1) * 0.5f; u[3][j] = g2;
               }
-              for (int nu = 0; nu < 4; ++nu)
+              for (int nu = 0; nu < 4; ++nu) {
                 memcpy(dw + (((size_t)co * nk8 + kc) * 12 + nu * 3 + dy) * 8, u[nu], sizeof(u[nu]));
+                // the same transformed weights as nearest bf16 hi / mid planes (nu = 2h + j)
+                uint16_t* d = dx3 + ((((size_t)co * nk16 + kc / 2) * 3 + dy) * 2 + (nu & 1)) * 64 + (nu >> 1) * 32 + (kc & 1) * 8;
+                for (int j = 0; j < 8; ++j) {
+                  const uint16_t hb = bf16_rne(u[nu][j]);
+                  d[j] = hb;
+                  d[16 + j] = bf16_rne(u[nu][j] - bf16_to_float(hb));
+                }
+              }
             }
           }
       }

@@ -149,7 +149,11 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                                         [Cout][chunk of 8][nu*3+dy][8] */,
                 CONV_TILE_SPLIT = 128 /* conv_halo_split_kernel (precision mode bf16x6): shape index = HaloTile,
                                          weights [Cout][chunk][tap][3 planes][16] bf16 */,
-                CONV_TILE_X3 = 512 /* with CONV_TILE_SPLIT: precision mode bf16x3 - planes hi, mid only, three products */ };
+                CONV_TILE_X3 = 512 /* precision mode bf16x3.  With CONV_TILE_SPLIT: conv_halo_split_kernel on planes hi, mid with
+                                      three products; with CONV_TILE_WINO: conv_winox3_kernel, shape index = WinoX3Tile,
+                                      weights [Cout][chunk][dy][j][h][plane][16] bf16 */ };
+// conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN
+enum WinoX3Tile { WX3_4x128_T22 = 0, WX3_4x64_T12 = 1, WX3_4x64_T21 = 3, WX3_4x32_T11 = 4 };   // all 8 waves
 // conv_wino_kernel tiles: patch rows x 64 pixels x output channels (waves M x N)
 enum WinoTile { WINO_4x128 = 0 /* 4x2 */, WINO_4x64 = 1 /* 4x1 */, WINO_4x128_W16 = 2 /* 4x4: 16 waves */,
                 WINO_4x64_W8 = 3 /* 4x2: 32 channels per wave */, WINO_4x32 = 4 /* 4x1 */, WINO_8x64_W16 = 5 /* 8x2 */,

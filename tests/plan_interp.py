@@ -98,6 +98,16 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 half = np.float32(0.5)
                 want_u = np.stack([g0, ((g0 + g2) + g1) * half, ((g0 + g2) - g1) * half, g2])
                 assert np.array_equal(ww, want_u), 'Winograd weight copy differs'
+                if op.get('wx_off', -1) >= 0:
+                    # bf16x3 copy of the transformed weights: [Cout][chunk16][dy][j][h][plane][16] bf16, nu = 2h + j,
+                    # hi + mid within 2^-17 of the fp32 value (nearest split)
+                    n16 = 12 * ct * co * 2
+                    raw = packed[op['wx_off']:op['wx_off'] + n16 // 2].view(np.uint16)
+                    pl = (raw.astype(np.uint32) << 16).view(np.float32).reshape(co, ct // 16, 3, 2, 2, 2, 16)
+                    got_u = pl.astype(np.float64).sum(axis=5)                      # [n][chunk][dy][j][h][16]
+                    got_u = got_u.transpose(4, 3, 2, 1, 5, 0).reshape(2, 2, 3, ct, co)   # [h][j][dy][c][n]
+                    got_u = got_u.reshape(4, 3, ct, co)                            # nu = 2h + j
+                    assert np.all(np.abs(got_u - want_u) <= np.abs(want_u.astype(np.float64)) * 2.0 ** -17), 'bf16x3 Winograd weight copy differs'
             if op.get('ws_off', -1) >= 0:
                 # bf16x6 copy: three bf16 planes [Cout][chunk][tap][plane][16] that add up to the weight EXACTLY
                 n16 = 9 * ct * co * 3

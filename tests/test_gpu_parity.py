@@ -96,6 +96,32 @@ def test_published_config2_256(published):
     assert fo.psnr(got, want) > 80.0
 
 
+@pytest.mark.parametrize('precision', [1, 2])
+def test_config2_256_in_the_opt_in_precision_modes(published, precision):
+    """BASELINE.json configs[1] through the default kernel-family rule of precision modes 1 (bf16x6) and 2 (bf16x3:
+    conv_winox3_kernel + conv_halo_split_kernel): every stage inside the same tolerances as the fp32 default, and the
+    tiled Interpolator path on top of it."""
+    from film_hip.engine import FilmEngine
+    from eval.interpolator import Interpolator
+    from oracle import film_oracle as fo
+    opt, w, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(w)
+    eng.set_option('precision', precision)
+    kinds = {(op.get('split', 0), op.get('wino', 0)) for op in eng.plan(1, 256, 256)['ops'] if op['kind'] == 'conv_mfma'}
+    assert ((1, 0) in kinds) if precision == 1 else ((0, 2) in kinds and (2, 0) in kinds), kinds
+    x0, x1 = _pair(1, 256, 256, seed=1)
+    got, want = _check_stages(eng, opt, w, x0, x1)
+    assert fo.psnr(got, want) > 80.0
+    eng.close()
+    x0, x1 = _pair(1, 120, 200, seed=17)
+    dt = np.full((1,), 0.5, np.float32)
+    it = Interpolator('', align=64, block_shape=[2, 2], weights=w)
+    it.engine.set_option('precision', precision)
+    want = fo.OracleInterpolator(w, align=64, block_shape=[2, 2])(x0, x1, dt)
+    assert np.abs(it(x0, x1, dt) - want).max() < IMAGE_TOL
+
+
 def test_published_batch_and_rect(published):
     opt, w, eng = published
     x0, x1 = _pair(2, 64, 128, seed=9)
@@ -302,21 +328,24 @@ def test_halo_kernels_on_every_level(published, precision, b, h, w):
     eng.close()
 
 
+@pytest.mark.parametrize('precision', [0, 2])
 @pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192)])
-def test_winograd_kernel_on_every_level(published, b, h, w):
-    """winograd = 2 forces conv_wino_kernel (F(2,3) along x) onto every 3x3 convolution with Cout % 64 == 0, i.e.
-    onto ragged patches (W < 64, odd pair counts, H not a multiple of 4): stage-by-stage parity with the oracle."""
+def test_winograd_kernel_on_every_level(published, precision, b, h, w):
+    """winograd = 2 forces conv_wino_kernel (precision 0) / conv_winox3_kernel (precision 2) - F(2,3) along x - onto
+    every 3x3 convolution, i.e. onto ragged patches (W < 64, odd pair counts, H not a multiple of 4): stage-by-stage
+    parity with the oracle."""
     from film_hip.engine import FilmEngine
     opt, wts, _ = published
     eng = FilmEngine(opt, device=0)
     eng.set_weights(wts)
     eng.set_option('winograd', 2)
+    eng.set_option('precision', precision)
     plan = eng.plan(b, h, w)
-    assert sum(op['wino'] for op in plan['ops']) > 30
+    assert sum(1 for op in plan['ops'] if op.get('wino') == (2 if precision else 1)) > 30
     x0, x1 = _pair(b, h, w, seed=53 + h + w)
     _check_stages(eng, opt, wts, x0, x1)
     eng.set_option('winograd', 0)
-    assert sum(op['wino'] for op in eng.plan(b, h, w)['ops']) == 0
+    assert sum(1 for op in eng.plan(b, h, w)['ops'] if op.get('wino')) == 0
     eng.close()
 
 

@@ -16,6 +16,7 @@
 #include "../frame-interpolation_amd/csrc/conv_igemm_impl.h"
 #include "experiments/conv_dma_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_split_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_winox3_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino_impl.h"
 #include "experiments/conv_wino16_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
@@ -59,12 +60,15 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 #define H(TH, BN, WM, WN, FL) {"halo " #TH "x32x" #BN " w" #WM "x" #WN " f" #FL, TH * 32, BN, 16, 2, conv_halo_launch<TH, BN, WM, WN, FL>}
 #define W(TH, BN, WM, WN) {"wino16 " #TH "x64x" #BN " w" #WM "x" #WN " f4", TH * 64, BN, 16, 4, conv_wino16_launch<TH, BN, WM, WN, 4>}
 #define W8(TH, BN, WM, WN) {"wino " #TH "x64x" #BN " w" #WM "x" #WN " f4", TH * 64, BN, 8, 5, conv_wino_launch<TH, BN, WM, WN, 4>}
+#define X(TH, BN, TM, TN) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f4", TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, 4>}
+#define XA(TH, BN, TM, TN, FL) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, FL>}
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
     V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4),
     W(4, 128, 4, 2), W(4, 64, 4, 1), W(4, 64, 4, 2), W(2, 128, 2, 2), W(4, 32, 4, 1),
     W8(4, 64, 4, 2), W8(4, 128, 4, 2), W8(4, 128, 4, 4), W8(4, 32, 4, 1), W8(8, 64, 8, 2), W8(8, 32, 8, 1), W8(2, 64, 2, 2),
-    S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
+    X(4, 128, 2, 2), XA(4, 128, 2, 2, 68), XA(4, 128, 2, 2, 132), XA(4, 128, 2, 2, 260), XA(4, 128, 2, 2, 516), XA(4, 128, 2, 2, 196), XA(4, 128, 2, 2, 452), XA(4, 128, 2, 2, 964), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
+    S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 128, 2, 2, 3), S(16, 128, 4, 2, 3), S(16, 64, 4, 1, 3), S(8, 64, 2, 1, 3), S(16, 128, 4, 1, 3), S(8, 64, 4, 1, 3), S(4, 128, 2, 2, 3), S(8, 32, 4, 1, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
     H(4, 128, 2, 2, 4), H(8, 64, 2, 2, 4), B(256, 64, 4, 1, 4), B(128, 64, 2, 2, 4), B(64, 64, 2, 2, 4),
     B(256, 128, 4, 2, 4), B(256, 32, 4, 1, 4), B(128, 32, 4, 1, 4),
@@ -130,6 +134,24 @@ __global__ void pack_wino8_kernel(const float* src, float* dst, int C, int N) {
     dst[(((size_t)n * (C / 8) + c / 8) * 12 + nu * 3 + dy) * 8 + c % 8] = u[nu];
 }
 
+// [tap*C + c][N] -> [N][chunk16][dy][j][h][plane][16] bf16: F(2,3) weight transform in fp32, then nearest hi / mid split
+__global__ void pack_winox3_kernel(const float* src, unsigned short* dst, int C, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)3 * C * N) return;
+  const int n = (int)(i % N);
+  const int c = (int)((i / N) % C), dy = (int)(i / ((size_t)N * C));
+  const float g0 = src[((size_t)(dy * 3 + 0) * C + c) * N + n], g1 = src[((size_t)(dy * 3 + 1) * C + c) * N + n],
+              g2 = src[((size_t)(dy * 3 + 2) * C + c) * N + n];
+  const float u[4] = {g0, ((g0 + g2) + g1) * 0.5f, ((g0 + g2) - g1) * 0.5f, g2};
+  auto rne = [](float v) { unsigned w = __float_as_uint(v); w += 0x7FFFu + ((w >> 16) & 1u); return w & 0xFFFF0000u; };
+  for (int nu = 0; nu < 4; ++nu) {
+    unsigned short* d = dst + ((((size_t)n * (C / 16) + c / 16) * 3 + dy) * 2 + (nu & 1)) * 64 + (nu >> 1) * 32 + c % 16;
+    const unsigned hb = rne(u[nu]);
+    d[0] = (unsigned short)(hb >> 16);
+    d[16] = (unsigned short)(rne(u[nu] - __uint_as_float(hb)) >> 16);
+  }
+}
+
 __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(a[i] - b[i]));
@@ -174,7 +196,7 @@ int main(int argc, char** argv) {
     const size_t M = (size_t)sh.NB * sh.H * sh.W;
     const size_t n_in = M * sh.C, n_w = (size_t)sh.ks * sh.ks * sh.C * sh.Cout, n_out = M * sh.Cout;
     float *d_in, *d_w, *d_wt, *d_wh, *d_ww, *d_w8, *d_b, *d_out, *d_zero, *d_ref, *d_md;
-    unsigned short* d_ws;
+    unsigned short *d_ws, *d_wx;
     CK(hipMalloc(&d_in, n_in * 4));
     CK(hipMalloc(&d_w, n_w * 4));
     CK(hipMalloc(&d_wt, n_w * 4));
@@ -182,6 +204,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_ws, n_w * 6));
     CK(hipMalloc(&d_ww, n_w * 4 * 12 / 9 + 64));
     CK(hipMalloc(&d_w8, n_w * 4 * 12 / 9 + 64));
+    CK(hipMalloc(&d_wx, n_w * 4 * 12 / 9 + 64));
     CK(hipMalloc(&d_ref, n_out * 4));
     CK(hipMalloc(&d_md, 4));
     CK(hipMalloc(&d_zero, 256));
@@ -193,6 +216,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, st, d_b, (size_t)sh.Cout, 3u, 0.1f);
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wt, sh.ks * sh.ks * sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_ww, sh.C, sh.Cout);
+    if (sh.ks == 3 && sh.C % 16 == 0) hipLaunchKernelGGL(pack_winox3_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_wx, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino8_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_w8, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_ws, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wh, sh.C, sh.Cout);
@@ -210,7 +234,7 @@ int main(int argc, char** argv) {
       if (only_variant && !strstr(v.name, only_variant)) continue;
       CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
       if (v.wkind >= 2 && sh.ks != 3) continue;
-      p.w = v.wkind == 5 ? d_w8 : v.wkind == 4 ? d_ww : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
+      p.w = v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 4 ? d_ww : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
       CK(v.fn(p, st));  // warm + correctness
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
       hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
@@ -242,7 +266,7 @@ int main(int argc, char** argv) {
              flops / best * 1e-9, rel < 1e-5 ? "ok" : "(ablation)", rel, maxdiff);
       fflush(stdout);
     }
-    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ww)); CK(hipFree(d_w8)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
+    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ww)); CK(hipFree(d_w8)); CK(hipFree(d_wx)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   return 0;
 }
