@@ -34,7 +34,7 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_winox
   constexpr int AH = (ITEMS + NT - 1) / NT;
   constexpr int BU = BN * 8;                   // 16-byte units of one weight stage
   constexpr int BLD = (BU + NT - 1) / NT;
-  static_assert(TH % TM == 0 && BN % (32 * TN) == 0 && AH <= 2, "bad tile");
+  static_assert(TH % TM == 0 && BN % (32 * TN) == 0 && AH <= 2 && ITEMS - NT <= NT / 2 && ITEMS >= NT, "bad tile");
   static_assert(2 * PW * TM * TN * 16 * 64 * 4 <= 2 * A_STAGE + 3 * B_STAGE, "exchange buffer does not fit");
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
@@ -72,13 +72,15 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_winox
   int a_lds[AH];              // byte offset of (hy, nu = 0, tp), channels 4q.. inside plane 0 of an A stage
 #pragma unroll
   for (int i = 0; i < AH; ++i) {
-    const int f = t + NT * i;
-    const bool slot = f < ITEMS;
-    const int q = f & 3, tp = (f >> 2) & 31, hy = slot ? (f >> 7) : 0;
+    // Threads past the last item repeat an item of the first half of the workgroup (same values to the same LDS
+    // address): the staging code then has no divergent branch (+8 % on the 528 -> 128 layer).
+    int f = t + NT * i;
+    if (f >= ITEMS) f -= NT / 2;
+    const int q = f & 3, tp = (f >> 2) & 31, hy = f >> 7;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + 2 * tp;
     a_y[i] = iy; a_x[i] = ix;
-    unsigned ok = slot ? 0x10u : 0u;
-    if (slot && iy >= 0 && iy < p.H)
+    unsigned ok = 0x10u;
+    if (iy >= 0 && iy < p.H)
       for (int j = 0; j < 4; ++j)
         if (ix + j >= 0 && ix + j < p.W) ok |= 1u << j;
     a_ok[i] = ok;
@@ -128,7 +130,6 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_winox
     }
   };
   auto store_item = [&](int i, int stage) {
-    if (!(a_ok[i] & 0x10u)) return;
     unsigned char* As = smem_b + stage * A_STAGE + a_lds[i];
     const bf4 v[4] = {araw[0] - araw[2], araw[1] + araw[2], araw[2] - araw[1], araw[1] - araw[3]};
 #pragma unroll
@@ -235,9 +236,21 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_winox
       if constexpr ((FLAGS & 64) == 0) fetch(std::integral_constant<int, (ST + 1) % 6>{}, ST == 5 ? a_next : a_cur);
       __builtin_amdgcn_sched_barrier(0);
       compute(st_c);
+      // The item's transform + split VALU work is left to the compiler's own placement: forced into an even
+      // interleave with the MFMAs (sched_group_barrier, one MFMA + 6 VALU) the kernel is 8 % slower.
+      if constexpr ((FLAGS & 1024) != 0) __builtin_amdgcn_sched_barrier(0);   // A/B: VALU strictly behind the MFMAs
+      if constexpr ((FLAGS & 128) == 0 && (ST & 1) == 1 && ST / 2 < AH) {
+        store_item(ST / 2, a_stage ^ 1);
+        if constexpr ((FLAGS & 2048) != 0) {   // A/B: forced even interleave
+#pragma unroll
+          for (int g = 0; g < 3 * TM * TN; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 64 / (3 * TM * TN) + 1, 0);
+          }
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
       if constexpr ((FLAGS & 256) == 0) store_b((ST + 2) % 3, ST & 1);
-      if constexpr ((FLAGS & 128) == 0) if constexpr ((ST & 1) == 1 && ST / 2 < AH) store_item(ST / 2, a_stage ^ 1);
       if constexpr ((FLAGS & 512) == 0) __syncthreads();
     };
     stage(std::integral_constant<int, 0>{});

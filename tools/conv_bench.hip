@@ -67,7 +67,7 @@ static Variant variants[] = {
     V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4),
     W(4, 128, 4, 2), W(4, 64, 4, 1), W(4, 64, 4, 2), W(2, 128, 2, 2), W(4, 32, 4, 1),
     W8(4, 64, 4, 2), W8(4, 128, 4, 2), W8(4, 128, 4, 4), W8(4, 32, 4, 1), W8(8, 64, 8, 2), W8(8, 32, 8, 1), W8(2, 64, 2, 2),
-    X(4, 128, 2, 2), XA(4, 128, 2, 2, 68), XA(4, 128, 2, 2, 132), XA(4, 128, 2, 2, 260), XA(4, 128, 2, 2, 516), XA(4, 128, 2, 2, 196), XA(4, 128, 2, 2, 452), XA(4, 128, 2, 2, 964), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
+    X(4, 128, 2, 2), XA(4, 128, 2, 2, 1028), XA(4, 128, 2, 2, 2052), XA(4, 64, 2, 1, 1028), XA(4, 64, 2, 1, 2052), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
     S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 128, 2, 2, 3), S(16, 128, 4, 2, 3), S(16, 64, 4, 1, 3), S(8, 64, 2, 1, 3), S(16, 128, 4, 1, 3), S(8, 64, 4, 1, 3), S(4, 128, 2, 2, 3), S(8, 32, 4, 1, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
     H(4, 128, 2, 2, 4), H(8, 64, 2, 2, 4), B(256, 64, 4, 1, 4), B(128, 64, 2, 2, 4), B(64, 64, 2, 2, 4),
