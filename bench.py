@@ -38,6 +38,7 @@ import torch  # noqa: E402
 CONV_FLOP_PER_PIXEL = 4246240.6875  # sum over the 171 convs, per padded input pixel
 WARP_BYTES_PER_PIXEL = 5201.58      # 22 warps, read once + flow + write once
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA; one fp32 product costs 6 (bf16x6) / 3 (bf16x3) bf16 products
 PEAK_HBM_GBS = 8000.0
 
 WORKLOADS = {
@@ -227,12 +228,19 @@ def main():
                 traffic = round(json.load(open(pmc_files[-1]))['hbm_bytes_per_launch'])
         except Exception:
             traffic = None
+        # the roofline the conv class is priced against: the fp32 MFMA peak in the default mode; in the opt-in
+        # split modes the dense bf16 MFMA peak divided by the bf16 products one fp32 product costs
+        peak = {0: PEAK_FP32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS / 6, 2: PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
         roofline = {
             'bound': 'mfma',
-            'kernel': 'conv class = conv_wino_kernel / conv_halo_kernel / conv_buf_kernel (fp32 v_mfma_f32_32x32x2_f32); '
-                      'FLOPs are the direct convolution\'s (SURVEY 8d) also where the Winograd F(2,3) kernel executes 1.5x fewer',
-            'achieved': round(conv_tflops, 3), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': round(conv_tflops / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': traffic,
+            'kernel': ('conv class = conv_wino_kernel / conv_halo_kernel / conv_buf_kernel (fp32 v_mfma_f32_32x32x2_f32); '
+                       'FLOPs are the direct convolution\'s (SURVEY 8d) also where the Winograd F(2,3) kernel executes 1.5x fewer')
+                      if not args.precision else
+                      ('conv class in the opt-in split mode = conv_winox3_kernel / conv_halo_split_kernel '
+                       '(v_mfma_f32_32x32x16_bf16, fp32 accumulate) + the fp32 kernels on the small / 2x2 layers; '
+                       'FLOPs are the direct fp32 convolution\'s, peak = dense bf16 MFMA peak / bf16 products per fp32 product'),
+            'achieved': round(conv_tflops, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+            'frac': round(conv_tflops / peak, 4), 'traffic': traffic if not args.precision else None,
             'traffic_note': 'bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 PMC passes' if traffic else None,
             'launches_per_step': conv['launches'],
             'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
@@ -240,7 +248,7 @@ def main():
             'algorithmic_flops_per_step': conv['flops'],
             'all_conv_flops_per_step': alg_flops,
             'share_of_kernel_time': round(conv['ms'] / total_ms, 4),
-            'executed': {'achieved': round(exec_tflops, 3), 'frac': round(exec_tflops / PEAK_FP32_MFMA_TFLOPS, 4),
+            'executed': {'achieved': round(exec_tflops, 3), 'frac': round(exec_tflops / peak, 4),
                          'note': 'FLOPs the matrix pipe executes (Winograd layers x2/3, folded 2x2 layers x9/16); `achieved` / '
                                  '`frac` above count the direct convolution (SURVEY 8d) and can exceed the fp32 MFMA peak'},
         }
