@@ -38,19 +38,34 @@ typedef float sf2 __attribute__((ext_vector_type(2)));
 // fp32 and the last one fits 8 significant bits, so hi + mid + lo == x EXACTLY (|x - hi| <= 2^-9 |x| is a multiple of
 // ulp(x) -> 16 bits; |x - hi - mid| <= 2^-17 |x| -> 8 bits).  Rounding (v_cvt_pk_bf16_f32) instead of truncation keeps
 // the pieces' signs uncorrelated with x, which is what makes the 2-plane "bf16x3" mode unbiased.
+// x - bf16 piece, for both halves of a packed pair: v_dot2c_f32_bf16 with the constant pairs (-1, 0) / (0, -1) reads the
+// bf16 halves in place (one instruction per element instead of shift / mask + subtract; x - hi is exact in fp32,
+// so the fused dot product returns exactly the same value)
+__device__ __forceinline__ sf2 conv_sub_bf16_pair(sf2 v, sbf2 p) {
+  // The constants go through opaque s_mov's: as literals hipcc folds the pair (-1, 0) = 0x0000BF80 into the INLINE
+  // constant "-1.0", which the instruction reads as 0xBF800000 = (0, -1) - both halves then subtract the high piece.
+  unsigned k0, k1;
+  asm("s_mov_b32 %0, 0xbf80" : "=s"(k0));
+  asm("s_mov_b32 %0, 0xbf800000" : "=s"(k1));
+  const sbf2 c0 = __builtin_bit_cast(sbf2, k0), c1 = __builtin_bit_cast(sbf2, k1);
+  sf2 r;
+  r.x = __builtin_amdgcn_fdot2_f32_bf16(p, c0, v.x, false);
+  r.y = __builtin_amdgcn_fdot2_f32_bf16(p, c1, v.y, false);
+  return r;
+}
+
 template <bool WITH_LO>
 __device__ __forceinline__ void conv_split4(bf4 x, su2& hi, su2& mid, su2& lo) {
   unsigned hp[2], mp[2], lp[2] = {0u, 0u};
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const sf2 v = {x[2 * j], x[2 * j + 1]};
-    hp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(v, sbf2));
-    const sf2 r = {v.x - __uint_as_float(hp[j] << 16), v.y - __uint_as_float(hp[j] & 0xFFFF0000u)};
-    mp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, sbf2));
-    if constexpr (WITH_LO) {
-      const sf2 q = {r.x - __uint_as_float(mp[j] << 16), r.y - __uint_as_float(mp[j] & 0xFFFF0000u)};
-      lp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(q, sbf2));
-    }
+    const sbf2 h = __builtin_convertvector(v, sbf2);
+    const sf2 r = conv_sub_bf16_pair(v, h);
+    const sbf2 m = __builtin_convertvector(r, sbf2);
+    hp[j] = __builtin_bit_cast(unsigned, h);
+    mp[j] = __builtin_bit_cast(unsigned, m);
+    if constexpr (WITH_LO) lp[j] = __builtin_bit_cast(unsigned, __builtin_convertvector(conv_sub_bf16_pair(r, m), sbf2));
   }
   hi.x = hp[0]; hi.y = hp[1];
   mid.x = mp[0]; mid.y = mp[1];
