@@ -28,6 +28,7 @@
 #include "conv_split_impl.h"
 #include "conv_wino_impl.h"
 #include "conv_winox3_impl.h"
+#include "conv_foldx3_impl.h"
 #include "conv_igemm_impl.h"
 
 template <int F>
@@ -108,10 +109,24 @@ static hipError_t launch_winox3(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+template <int F>
+static hipError_t launch_foldx3(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case FX3_4x64: return conv_foldx3_launch<4, 64, 4, 1, F>(p, s);
+    case FX3_8x64: return conv_foldx3_launch<8, 64, 8, 1, F>(p, s);
+    case FX3_4x128: return conv_foldx3_launch<4, 128, 4, 2, F>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
+  if (tile & CONV_TILE_FOLDX3) {
+    if (p.ksize != 2 || p.fold != 2) return hipErrorInvalidValue;
+    return (tile & CONV_TILE_XCD) ? launch_foldx3<CONV_B_XCD_M>(p, shape, s) : launch_foldx3<0>(p, shape, s);
+  }
   if (tile & CONV_TILE_WINO) {
     if (p.ksize != 3) return hipErrorInvalidValue;
     if (tile & CONV_TILE_X3) return (tile & CONV_TILE_XCD) ? launch_winox3<CONV_B_XCD_M>(p, shape, s) : launch_winox3<0>(p, shape, s);

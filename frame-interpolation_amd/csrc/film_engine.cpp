@@ -72,6 +72,7 @@ struct OpDesc {
   int64_t fold_woff[4] = {0, 0, 0, 0};  // fold == 2: weight offset of phase q relative to w_off
   int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
   int64_t wx_off = -1;                // conv: ... and its 2-plane bf16 split (precision mode bf16x3, conv_winox3_kernel)
+  int64_t wfx_off = -1;               // conv: phase-summed weights of a folded 2x2 layer as bf16 hi / mid (conv_foldx3_kernel)
   int wino = 0;                       // conv: 1 = runs on conv_wino_kernel, 2 = on conv_winox3_kernel (precision bf16x3)
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
   int lane = 0;                       // graph replay: 0 = main stream, 1 = side stream (small / HBM-bound work)
@@ -100,6 +101,8 @@ struct LayerPack {
   int64_t wf_off = -1;       // 2x2 layers behind a nearest upsample: the four sub-pixel phases, pre-summed weights,
                              //     phase (py,px) at wf_off + fold_phase_off(py,px): [Cout][ntaps_p * ctot], 9*ctot*cout in all
   int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/8][12][8]
+  int64_t wfx_off = -1;      // 2x2 layers after an upsample: the phase-summed weights as bf16 hi / mid for conv_foldx3_kernel,
+                             //     [Cout][ctot/16][9 (tap, phase) steps][plane][16] bf16
   int64_t wx_off = -1;       // ... and the transformed copy split into bf16 hi / mid for conv_winox3_kernel,
                              //     [Cout][ctot/16][dy][j][h][plane][16] bf16 (nu = 2h + j)
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
@@ -307,7 +310,10 @@ void build_layers(film_t* h) {
     L.b_off = off;
     off += L.cout;
     off = (off + 3) & ~int64_t(3);
-    if (L.has_fold()) { L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; off = (off + 3) & ~int64_t(3); }
+    if (L.has_fold()) {
+      L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; off = (off + 3) & ~int64_t(3);
+      L.wfx_off = off; off += (int64_t)9 * L.ctot() * L.cout; off = (off + 3) & ~int64_t(3);
+    }
     if (L.has_halo()) {
       L.wh_off = off; off += L.packed_rows() * L.cout;
       off = (off + 3) & ~int64_t(3);
@@ -389,7 +395,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off;
     if (h->opt_fold && L.wf_off >= 0 && op.nseg == 1 && segs[0].up && !(H & 1) && !(W & 1)) {
       // nearest x2 + 2x2 'same' conv == four phase convolutions on the low-resolution input: kernel tap (dy, dx) of
       // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
@@ -407,6 +413,10 @@ struct Planner {
       for (int q = 0; q < 4; ++q) { f.fold_woff[q] = rel; rel += (int64_t)((q >> 1) + 1) * ((q & 1) + 1) * ctot * L.cout; }
       f.halo = f.split = f.wino = 0;
       f.tile = choose_tile((int64_t)NB * f.H * f.W * 2, L.cout);
+      if (h->opt_precision == 2 && L.wfx_off >= 0 && L.cout % 64 == 0 && ((int64_t)f.H * f.W >= 2048 || h->opt_halo_all)) {
+        f.split = 2;   // precision mode bf16x3: one halo-staged patch, nine (tap, phase) steps (conv_foldx3_kernel)
+        f.tile = FX3_4x64 | CONV_TILE_FOLDX3 | CONV_TILE_XCD;
+      }
       f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin;   // algorithmic FLOPs of the reference op
       f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout);
       P->ops.push_back(f);
@@ -740,7 +750,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
       p.ksize = op.ksize;
-      p.w = wts + ((op.tile & CONV_TILE_WINO) ? ((op.tile & CONV_TILE_X3) ? op.wx_off : op.ww_off) : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
+      p.w = wts + ((op.tile & CONV_TILE_FOLDX3) ? op.wfx_off : (op.tile & CONV_TILE_WINO) ? ((op.tile & CONV_TILE_X3) ? op.wx_off : op.ww_off) : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
                    : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
       p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
@@ -832,6 +842,13 @@ std::vector<int> wino_candidates(int Cout) {
   return out;
 }
 
+std::vector<int> foldx3_candidates(int Cout) {
+  std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{FX3_4x64, FX3_8x64, FX3_4x128} : std::vector<int>{FX3_4x64, FX3_8x64};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_FOLDX3); out.push_back(sh | CONV_TILE_FOLDX3 | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> winox3_candidates(int Cout) {
   std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{WX3_4x128_T22, WX3_4x64_T12, WX3_4x64_T21}
                             : Cout % 64 == 0 ? std::vector<int>{WX3_4x64_T12, WX3_4x64_T21, WX3_4x32_T11}
@@ -885,7 +902,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -1011,7 +1028,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
@@ -1218,6 +1235,10 @@ int film_finalize(film_t* h) {
         }
       if (L.wf_off >= 0) {  // sub-pixel phases of upsample + 2x2: weights of the taps that read the same input pixel, summed
         float* df = h->packed_host.data() + L.wf_off;
+        uint16_t* dfx = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.wfx_off);
+        const size_t nk16f = (size_t)ct / 16;
+        // step of (tap a*2+b, phase py*2+px) in conv_foldx3_kernel's order (taps 00 00 00 | 00 01 01 | 10 10 11)
+        static const int kFoldStep[4][4] = {{0, 1, 2, 3}, {-1, 4, -1, 5}, {-1, -1, 6, 7}, {-1, -1, -1, 8}};
         for (int py = 0; py < 2; ++py)
           for (int px = 0; px < 2; ++px) {
             const int nt = (py + 1) * (px + 1);
@@ -1234,6 +1255,11 @@ int film_finalize(film_t* h) {
                       for (int dx = 0; dx < 2; ++dx)
                         if ((py & dy) == a && (px & dx) == b) acc += src[((size_t)(dy * 2 + dx) * L.cin + ref) * L.cout + co];
                     df[(size_t)co * kph + (size_t)t * ct + ci] = acc;
+                    const int step = kFoldStep[a * 2 + b][py * 2 + px];
+                    uint16_t* d = dfx + (((size_t)co * nk16f + ci / 16) * 9 + step) * 32 + ci % 16;
+                    const uint16_t hb = bf16_rne(acc);
+                    d[0] = hb;
+                    d[16] = bf16_rne(acc - bf16_to_float(hb));
                   }
                 }
             df += kph * L.cout;

@@ -52,6 +52,12 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             x = np.ascontiguousarray(_view(arena, sg['v'], nb, h, w))
             ct, co = op['Ctot'], op['Cout']
             outv = _view(arena, op['out'], nb, 2 * h, 2 * w)
+            wfx = None
+            if op.get('wfx_off', -1) >= 0:
+                # bf16x3 copy for conv_foldx3_kernel: [Cout][chunk16][9 (tap, phase) steps][plane][16] bf16
+                raw = packed[op['wfx_off']:op['wfx_off'] + 9 * ct * co].view(np.uint16)
+                wfx = (raw.astype(np.uint32) << 16).view(np.float32).reshape(co, ct // 16, 9, 2, 16).astype(np.float64).sum(axis=3)
+                fold_step = {(0, 0): 0, (0, 1): 1, (0, 2): 2, (0, 3): 3, (1, 1): 4, (1, 3): 5, (2, 2): 6, (2, 3): 7, (3, 3): 8}
             for q in range(4):
                 py, px = q >> 1, q & 1
                 taps = [(a, b) for a in range(py + 1) for b in range(px + 1)]
@@ -59,6 +65,10 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 wt = packed[off:off + len(taps) * ct * co].reshape(co, len(taps), ct)
                 acc = np.zeros((nb, h, w, co), np.float32)
                 for t, (a, b) in enumerate(taps):
+                    if wfx is not None:
+                        got = wfx[:, :, fold_step[(a * 2 + b, q)], :].reshape(co, ct)
+                        want = wt[:, t].astype(np.float64)
+                        assert np.all(np.abs(got - want) <= np.abs(want) * 2.0 ** -17), 'bf16x3 fold weight copy differs'
                     sh = np.zeros_like(x)
                     sh[:, :h - a, :w - b] = x[:, a:, b:]          # zero beyond the bottom / right edge
                     acc += (sh.reshape(-1, ct) @ wt[:, t].T).reshape(nb, h, w, co)

@@ -110,6 +110,8 @@ def test_config2_256_in_the_opt_in_precision_modes(published, precision):
     eng.set_option('precision', precision)
     kinds = {(op.get('split', 0), op.get('wino', 0)) for op in eng.plan(1, 256, 256)['ops'] if op['kind'] == 'conv_mfma'}
     assert ((1, 0) in kinds) if precision == 1 else ((0, 2) in kinds and (2, 0) in kinds), kinds
+    if precision == 2:
+        assert any(op.get('fold') and op['split'] == 2 for op in eng.plan(1, 256, 256)['ops'])   # conv_foldx3_kernel
     x0, x1 = _pair(1, 256, 256, seed=1)
     got, want = _check_stages(eng, opt, w, x0, x1)
     assert fo.psnr(got, want) > 80.0
@@ -322,7 +324,9 @@ def test_halo_kernels_on_every_level(published, precision, b, h, w):
     plan = eng.plan(b, h, w)
     key = 'split' if precision else 'halo'
     n3 = sum(1 for op in plan['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 3 and not op['c3'])
-    assert sum(1 for op in plan['ops'] if op.get(key)) == n3 > 40
+    assert sum(1 for op in plan['ops'] if op.get(key) and op['ksize'] == 3) == n3 > 40
+    if precision == 2:   # ... and conv_foldx3_kernel onto every folded upsample + 2x2 layer
+        assert all(op['split'] == 2 for op in plan['ops'] if op.get('fold'))
     x0, x1 = _pair(b, h, w, seed=47 + h + w)
     _check_stages(eng, opt, wts, x0, x1)
     eng.close()
