@@ -448,9 +448,8 @@ struct Planner {
       // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  Standalone (tools/conv_bench.hip) the Winograd form
       // wins on the deep 128-channel-tile layers (427 vs 367 TFLOP/s at K = 22 032) and loses on 64 -> 64 at full
       // resolution (250 vs 312); in the whole 1080p step taking every Cout % 64 == 0 layer measured best
-      // (34.4 ms vs 34.9 ms with Cout % 128 == 0 only vs 35.3 ms without the kernel).  FILM_WX3_MINCOUT: tuning knob.
-      static const int min_cout = getenv("FILM_WX3_MINCOUT") ? atoi(getenv("FILM_WX3_MINCOUT")) : 64;
-      if (L.cout % 128 == 0 || (L.cout >= min_cout && L.cout % 64 == 0) || min_cout <= 32 || h->opt_wino == 2) op.split = 0, op.wino = 2;
+      // (34.4 ms vs 34.9 ms with Cout % 128 == 0 only vs 35.3 ms without the kernel).
+      if (L.cout % 64 == 0 || h->opt_wino == 2) op.split = 0, op.wino = 2;
       else if (op.split == 2) op.wino = 0;
     }
     if (op.split || op.wino) op.halo = 0;

@@ -161,6 +161,38 @@ def test_plan_interpreter_matches_oracle_published_64():
     assert abs(warp_bytes / (64 * 64) - 5201.58) / 5201.58 < 1e-3
 
 
+def test_precision_modes_choose_kernel_families_by_shape_only():
+    """The kernel family of a layer is a pure function of (layer shape, precision option) - never of batch size or
+    timing.  Mode 0: no split kernels; mode 1: conv_halo_split_kernel (split = 1); mode 2: conv_winox3_kernel
+    (wino = 2) on the Cout % 64 == 0 layers, conv_halo_split_kernel<..,3> (split = 2) on the others, conv_foldx3_kernel
+    (fold with split = 2) on the decoder's large upsample + 2x2 layers; tile ids carry the matching flags."""
+    from film_hip.engine import FilmEngine, FilmError
+    from film_hip.options import PUBLISHED
+    WINO, SPLIT, X3, FOLDX3 = 256, 128, 512, 1024
+    eng = FilmEngine(PUBLISHED, device=-1)
+    fam = {}
+    for mode in (0, 1, 2):
+        eng.set_option('precision', mode)
+        per_batch = []
+        for b in (1, 4):
+            ops = [op for op in eng.plan(b, 256, 448)['ops'] if op['kind'] == 'conv_mfma']
+            per_batch.append([(op['tag'], op['split'], op['wino'], op['fold']) for op in ops])
+            for op in ops:
+                t = op['tile']
+                assert bool(t & FOLDX3) == (op['fold'] == 2 and op['split'] == 2)
+                assert bool(t & WINO) == (op['wino'] != 0) and bool(t & SPLIT) == (op['split'] != 0 and not op['fold'])
+                assert bool(t & X3) == (op['wino'] == 2 or (op['split'] == 2 and not op['fold']))
+        assert per_batch[0] == per_batch[1]
+        fam[mode] = per_batch[0]
+    assert all(s == 0 and w in (0, 1) for _, s, w, _ in fam[0])
+    assert any(s == 1 for _, s, _, _ in fam[1]) and all(w == 0 for _, s, w, _ in fam[1] if s)
+    assert any(w == 2 for _, _, w, _ in fam[2]) and any(s == 2 and not f for _, s, _, f in fam[2])
+    assert any(s == 2 and f == 2 for _, s, _, f in fam[2])
+    assert not any(s == 1 or w == 1 and s for _, s, w, _ in fam[2])
+    with pytest.raises(FilmError):
+        eng.set_option('precision', 3)
+
+
 def test_plan_shape_errors(tiny_weights):
     from film_hip.engine import FilmEngine, FilmError, FILM_ERR_INVALID
     from film_hip.options import TINY
