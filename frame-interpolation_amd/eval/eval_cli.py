@@ -88,12 +88,13 @@ def main(argv: Optional[List[str]] = None) -> int:
     ap.add_argument('--block_height', type=int, default=1)
     ap.add_argument('--block_width', type=int, default=1)
     ap.add_argument('--device', type=int, default=0, help='HIP device ordinal.')
+    ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2], help='engine precision mode: 0 fp32 MFMA, 1 bf16x6, 2 bf16x3.')
     args = ap.parse_args(argv)
     triplets = find_triplets(args.triplet_dir)
     if not triplets:
         print(f'no image triplets under {args.triplet_dir}', file=sys.stderr)
         return 1
-    it = interpolator_lib.Interpolator(args.model_path, args.align, [args.block_height, args.block_width], device=args.device)
+    it = interpolator_lib.Interpolator(args.model_path, args.align, [args.block_height, args.block_width], device=args.device, precision=args.precision)
     totals = run_evaluation(it, triplets, args.output_dir, args.max_examples, args.metrics, args.output_frames,
                             args.model_path, args.triplet_dir)
     print('mean,', totals)

@@ -98,7 +98,7 @@ class Interpolator:
                align: Optional[int] = None,
                block_shape: Optional[List[int]] = None,
                *, device: int = 0, options: Optional[Options] = None,
-               weights=None) -> None:
+               weights=None, precision: int = 0) -> None:
     """Loads the weights of a saved model into a HIP engine.
 
     Args:
@@ -109,6 +109,8 @@ class Interpolator:
       device: (extension) HIP device ordinal.
       options: (extension) architecture hyper-parameters; default = published film_net.
       weights: (extension) an already loaded {name: array} dict; model_path is then ignored.
+      precision: (extension) engine precision mode: 0 = fp32 MFMA (default), 1 = bf16x6, 2 = bf16x3
+        (film_set_option "precision", include/film_hip.h).
     """
     self._options = options or PUBLISHED
     if weights is None:
@@ -116,6 +118,8 @@ class Interpolator:
     weights_lib.validate_weights(weights, self._options)
     self._engine = FilmEngine(self._options, device=device)
     self._engine.set_weights(weights)
+    if precision:
+      self._engine.set_option('precision', int(precision))
     self._align = align or None
     self._block_shape = block_shape or None
 

@@ -38,6 +38,8 @@ def build_parser() -> argparse.ArgumentParser:
                     help='If >1, pad the input size so it is evenly divisible by this value.')
     ap.add_argument('--block_height', type=int, default=1, help='Number of patches along height.')
     ap.add_argument('--block_width', type=int, default=1, help='Number of patches along width.')
+    ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
+                    help='(extension) engine precision mode: 0 fp32 MFMA, 1 bf16x6, 2 bf16x3.')
     ap.add_argument('--output_video', action='store_true', default=False,
                     help='If true, creates a video of the frames in the interpolated_frames/ subdirectory')
     return ap
@@ -94,7 +96,7 @@ def main(argv=None) -> None:
     args = build_parser().parse_args(argv)
     if args.output_video:
         util.get_ffmpeg_path()
-    it = interpolator_lib.Interpolator(args.model_path, args.align, [args.block_height, args.block_width])
+    it = interpolator_lib.Interpolator(args.model_path, args.align, [args.block_height, args.block_width], precision=args.precision)
     for directory in sorted(glob.glob(args.pattern)):
         if os.path.isdir(directory):
             n = process_directory(directory, it, args)

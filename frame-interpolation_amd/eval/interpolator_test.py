@@ -28,6 +28,8 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument('--block_height', type=int, default=1,
                     help='An int >= 1, number of patches along height, patch_height = height//block_height, '
                          'should be evenly divisible.')
+    ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
+                    help='(extension) engine precision mode: 0 fp32 MFMA, 1 bf16x6, 2 bf16x3.')
     ap.add_argument('--block_width', type=int, default=1,
                     help='An int >= 1, number of patches along width, patch_width = width//block_width, '
                          'should be evenly divisible.')
@@ -37,7 +39,7 @@ def build_parser() -> argparse.ArgumentParser:
 def run(args) -> str:
     """reference _run_interpolator (eval/interpolator_test.py:73-99)."""
     it = interpolator_lib.Interpolator(model_path=args.model_path, align=args.align,
-                                       block_shape=[args.block_height, args.block_width])
+                                       block_shape=[args.block_height, args.block_width], precision=args.precision)
     first = util.read_image(args.frame1)[np.newaxis]
     second = util.read_image(args.frame2)[np.newaxis]
     half = np.full(shape=(1,), fill_value=0.5, dtype=np.float32)
