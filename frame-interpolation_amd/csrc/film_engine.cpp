@@ -445,11 +445,11 @@ struct Planner {
               ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
                px >= 100000 || h->opt_wino == 2);
     if (op.wino && h->opt_precision == 2 && (op.split == 2 || h->opt_wino == 2)) {
-      // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  Standalone (tools/conv_bench.hip) the Winograd form
-      // wins on the deep 128-channel-tile layers (427 vs 367 TFLOP/s at K = 22 032) and loses on 64 -> 64 at full
-      // resolution (250 vs 312); in the whole 1080p step taking every Cout % 64 == 0 layer measured best
-      // (34.4 ms vs 34.9 ms with Cout % 128 == 0 only vs 35.3 ms without the kernel).
-      if (L.cout % 64 == 0 || h->opt_wino == 2) op.split = 0, op.wino = 2;
+      // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  The Winograd form wins with the 2 x 2 wave block of
+      // its 128-channel tile (0.88-0.94x the time of conv_halo_split_kernel<..,3> per layer, 427 vs 367 TFLOP/s at
+      // K = 22 032) and loses with the 64-channel tiles (1.08-1.30x: twice the A staging per MFMA) - per-op profiles of
+      // the two plans and tools/conv_bench.hip agree.
+      if (L.cout % 128 == 0 || h->opt_wino == 2) op.split = 0, op.wino = 2;
       else if (op.split == 2) op.wino = 0;
     }
     if (op.split || op.wino) op.halo = 0;

@@ -164,7 +164,7 @@ def test_plan_interpreter_matches_oracle_published_64():
 def test_precision_modes_choose_kernel_families_by_shape_only():
     """The kernel family of a layer is a pure function of (layer shape, precision option) - never of batch size or
     timing.  Mode 0: no split kernels; mode 1: conv_halo_split_kernel (split = 1); mode 2: conv_winox3_kernel
-    (wino = 2) on the Cout % 64 == 0 layers, conv_halo_split_kernel<..,3> (split = 2) on the others, conv_foldx3_kernel
+    (wino = 2) on the Cout % 128 == 0 layers, conv_halo_split_kernel<..,3> (split = 2) on the others, conv_foldx3_kernel
     (fold with split = 2) on the decoder's large upsample + 2x2 layers; tile ids carry the matching flags."""
     from film_hip.engine import FilmEngine, FilmError
     from film_hip.options import PUBLISHED
