@@ -85,20 +85,33 @@ __global__ __launch_bounds__(256) void flow_head_kernel(FlowHeadParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-wise kernels (pool, warp): grid = (units of a row / 256, rows, images), so that the only per-thread division is
+// "unit of the row -> (pixel x, channel group g)": a float multiply by 1/G and one correction step (exact for
+// units < 2^24; the launchers check) instead of three 64-bit divisions by run-time values, which made these
+// kernels instruction bound (warp_vec_kernel: 640 instructions for four 16-byte loads and one store).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void split_unit(unsigned i, int G, int& x, int& g) {
+  const float rg = 1.0f / (float)G;
+  x = (int)((float)i * rg);   // off by at most one
+  int r = (int)i - x * G;
+  if (r < 0) { --x; r += G; }
+  else if (r >= G) { ++x; r -= G; }
+  g = r;
+}
+
+// ------------------------------------------------------------------------------------------------
 // pool2x2: thread = (output pixel, float4 channel group) or (output pixel) for C == 3.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pool_vec_kernel(PoolParams p) {
   const int G = p.C >> 2;
   const int Ho = p.H >> 1, Wo = p.W >> 1;
-  const int64_t total = (int64_t)p.NB * Ho * Wo * G;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int g = (int)(idx % G);
-  const int64_t pix = idx / G;
-  const int x = (int)(pix % Wo);
-  const int64_t t2 = pix / Wo;
-  const int y = (int)(t2 % Ho);
-  const int64_t b = t2 / Ho;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)(Wo * G)) return;
+  int x, g;
+  split_unit(i, G, x, g);
+  const int y = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t pix = (b * Ho + y) * Wo + x;
   const float* s00 = p.in + ((b * p.H + 2 * y) * p.W + 2 * x) * p.istride + g * 4;
   const float4 a = *reinterpret_cast<const float4*>(s00);
   const float4 bq = *reinterpret_cast<const float4*>(s00 + p.istride);
@@ -114,13 +127,11 @@ __global__ __launch_bounds__(256) void pool_vec_kernel(PoolParams p) {
 
 __global__ __launch_bounds__(256) void pool_c3_kernel(PoolParams p) {
   const int Ho = p.H >> 1, Wo = p.W >> 1;
-  const int64_t total = (int64_t)p.NB * Ho * Wo;
-  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= total) return;
-  const int x = (int)(pix % Wo);
-  const int64_t t2 = pix / Wo;
-  const int y = (int)(t2 % Ho);
-  const int64_t b = t2 / Ho;
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (x >= Wo) return;
+  const int y = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t pix = (b * Ho + y) * Wo + x;
   const float* s00 = p.in + ((b * p.H + 2 * y) * p.W + 2 * x) * p.istride;
   const float* s10 = s00 + (int64_t)p.W * p.istride;
 #pragma unroll
@@ -199,15 +210,13 @@ __device__ __forceinline__ float lerp3(float tl, float tr, float bl, float br, f
 
 __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int G = p.C >> 2;
-  const int64_t total = (int64_t)p.NB * p.H * p.W * G;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int g = (int)(idx % G);
-  const int64_t pix = idx / G;
-  const int x = (int)(pix % p.W);
-  const int64_t t2 = pix / p.W;
-  const int y = (int)(t2 % p.H);
-  const int64_t b = t2 / p.H;
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= (unsigned)(p.W * G)) return;
+  int x, g;
+  split_unit(i, G, x, g);
+  const int y = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t pix = (b * p.H + y) * p.W + x;
   const float2 fl = reinterpret_cast<const float2*>(p.flow)[pix];
   const float qy = (float)y + p.fscale * fl.y;
   const float qx = (float)x + p.fscale * fl.x;
@@ -229,13 +238,11 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
 }
 
 __global__ __launch_bounds__(256) void warp_c3_kernel(WarpParams p) {
-  const int64_t total = (int64_t)p.NB * p.H * p.W;
-  const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (pix >= total) return;
-  const int x = (int)(pix % p.W);
-  const int64_t t2 = pix / p.W;
-  const int y = (int)(t2 % p.H);
-  const int64_t b = t2 / p.H;
+  const int x = (int)(blockIdx.x * 256u + threadIdx.x);
+  if (x >= p.W) return;
+  const int y = blockIdx.y;
+  const int64_t b = blockIdx.z;
+  const int64_t pix = (b * p.H + y) * p.W + x;
   const float2 fl = reinterpret_cast<const float2*>(p.flow)[pix];
   const float qy = (float)y + p.fscale * fl.y;
   const float qx = (float)x + p.fscale * fl.x;
@@ -295,11 +302,14 @@ hipError_t film_launch_flow_head(const FlowHeadParams& p, hipStream_t s) {
 }
 
 hipError_t film_launch_pool(const PoolParams& p, hipStream_t s) {
-  const int64_t opix = (int64_t)p.NB * (p.H / 2) * (p.W / 2);
+  const int Ho = p.H / 2, Wo = p.W / 2;
+  const int64_t units = p.C == 3 ? Wo : (int64_t)Wo * (p.C / 4);
+  if (units >= (1 << 24) || Ho > 65535 || p.NB > 65535) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((units + 255) / 256), (unsigned)Ho, (unsigned)p.NB);
   if (p.C == 3) {
-    hipLaunchKernelGGL(pool_c3_kernel, dim3(blocks_for(opix)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pool_c3_kernel, grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL(pool_vec_kernel, dim3(blocks_for(opix * (p.C / 4))), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(pool_vec_kernel, grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }
@@ -316,11 +326,13 @@ hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s) {
 }
 
 hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
-  const int64_t npix = (int64_t)p.NB * p.H * p.W;
+  const int64_t units = p.C == 3 ? p.W : (int64_t)p.W * (p.C / 4);
+  if (units >= (1 << 24) || p.H > 65535 || p.NB > 65535) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB);
   if (p.C == 3) {
-    hipLaunchKernelGGL(warp_c3_kernel, dim3(blocks_for(npix)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(warp_c3_kernel, grid, dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL(warp_vec_kernel, dim3(blocks_for(npix * (p.C / 4))), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(warp_vec_kernel, grid, dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }
