@@ -294,7 +294,7 @@ def main():
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
                 result['precision_mode_' + name] = {
-                    'value': round(args.steps / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                    'value': round(args.steps * pairs / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
                     'max_abs_diff_vs_f32_mode': float((out2 - ref_out).abs().max()),
                     'note': f'opt-in (film_set_option precision={mode}: {what}, fp32 accumulate); '
                             'the headline value above is the fp32-MFMA default',
