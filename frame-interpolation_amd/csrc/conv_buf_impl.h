@@ -90,6 +90,8 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
   auto tap_dy = [&](int tp) { return p.fold == 2 ? (fpx ? tp >> 1 : tp) : p.fold ? (int)p.tdy[tp] : tp / ksz - pad; };
   auto tap_dx = [&](int tp) { return p.fold == 2 ? (fpx ? tp & 1 : 0) : p.fold ? (int)p.tdx[tp] : tp % ksz - pad; };
   const float* const wbase = p.fold == 2 ? p.w + p.fold_woff[blockIdx.z] : p.w;
+  const int ksplit = p.fold ? 1 : (p.ksplit > 1 ? p.ksplit : 1);
+  const int split = ksplit > 1 ? (int)blockIdx.z : 0;
   const int HW = p.H * p.W;
   int ab[AR], ay[AR], ax[AR];
   unsigned amask[AR];                      // bit tap: the tap's source pixel is inside the image (and m < M)
@@ -169,8 +171,18 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
     bf4 b[BR];
   };
   Stage sx, sy;
-  int kstep = 0;
-  const int nsteps = ntaps * (p.Ctot / 16);
+  const int nsteps_all = ntaps * (p.Ctot / 16);
+  const int k_begin = (int)((long long)split * nsteps_all / ksplit);
+  const int nsteps = (int)((long long)(split + 1) * nsteps_all / ksplit);   // end of this split's K range
+  int kstep = k_begin;
+  if (k_begin > 0) {   // seek (tap, segment, chunk) to step k_begin
+    const int spt = p.Ctot / 16;
+    tap = k_begin / spt;
+    int rem = (k_begin - tap * spt) * 16;
+    sg = 0;
+    while (rem >= p.seg[sg].C) { rem -= p.seg[sg].C; ++sg; }
+    c0 = rem;
+  }
   // loads of K-step `kstep`; past the end: A from nowhere (zeros), B repeats the last step (finite x 0)
   auto load_global = [&](Stage& st) {
     const unsigned asoff = (unsigned)c0 * 4u;
@@ -241,7 +253,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
   load_global(sy);  // step 1
   store_lds(sx, 0);
   __syncthreads();
-  for (int s = 0; s < nsteps; s += 2) {
+  for (int s = k_begin; s < nsteps; s += 2) {
     load_global(sx);  // step s+2
     __builtin_amdgcn_sched_barrier(0);
     compute(0);
@@ -269,6 +281,10 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = m0 + wm * WTM + mt * 32 + row;
         if (m < p.M) {
+          if (ksplit > 1) {  // raw partial sum; bias + activation in conv_splitk_reduce_kernel
+            p.part[((size_t)split * p.M + m) * p.Cout + n] = acc[mt][nt][r];
+            continue;
+          }
           float v = acc[mt][nt][r] + bv;
           if (p.leaky) v = v > 0.f ? v : 0.2f * v;
           size_t opix = (size_t)m;
@@ -297,7 +313,8 @@ hipError_t conv_buf_launch(const ConvParams& p, hipStream_t s) {
       if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
-  dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.fold == 2 ? 4 : 1);
+  if (p.ksplit > 1 && p.fold) return hipErrorInvalidValue;
+  dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.fold == 2 ? 4 : (p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, p);
   return hipGetLastError();
 }

@@ -121,6 +121,29 @@ static hipError_t launch_foldx3(const ConvParams& p, int shape, hipStream_t s) {
 
 static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
 
+// Second half of a split-K convolution (film_kernels.h, ConvParams::ksplit): out = act(bias + part[0] + part[1] + ...),
+// partials added in split order.  Thread = one float4 of an output pixel.
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                                 float* __restrict__ out, int M, int Cout, int ostride,
+                                                                 int S, int leaky) {
+  const int G = Cout >> 2;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (unsigned)M * (unsigned)G) return;
+  const unsigned m = idx / (unsigned)G, g = idx - m * (unsigned)G;
+  const size_t plane = (size_t)M * Cout;
+  const float4* src = reinterpret_cast<const float4*>(part + (size_t)m * Cout + g * 4);
+  float4 a = *reinterpret_cast<const float4*>(bias + g * 4);
+  for (int sidx = 0; sidx < S; ++sidx) {
+    const float4 v = src[(size_t)sidx * (plane >> 2)];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (leaky) {
+    a.x = a.x > 0.f ? a.x : 0.2f * a.x; a.y = a.y > 0.f ? a.y : 0.2f * a.y;
+    a.z = a.z > 0.f ? a.z : 0.2f * a.z; a.w = a.w > 0.f ? a.w : 0.2f * a.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)m * ostride + g * 4) = a;
+}
+
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
   if (tile & CONV_TILE_FOLDX3) {
@@ -143,5 +166,11 @@ hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   }
   if (tile & CONV_TILE_C3)
     return (tile & CONV_TILE_XCD) ? launch_c3<CONV_F_XCD_M>(p, shape, s) : launch_c3<0>(p, shape, s);
-  return (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
+  const hipError_t e = (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
+  if (e != hipSuccess || p.ksplit <= 1) return e;
+  if (!p.part || (p.Cout & 3) || (long long)p.M * (p.Cout >> 2) >= (1ll << 32)) return hipErrorInvalidValue;
+  const unsigned units = (unsigned)p.M * (unsigned)(p.Cout >> 2);
+  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((units + 255) / 256), dim3(256), 0, s, p.part, p.bias, p.out, p.M, p.Cout,
+                     p.ostride, p.ksplit, p.leaky);
+  return hipGetLastError();
 }

@@ -67,6 +67,8 @@ struct OpDesc {
   int64_t w2_off = 0, b2_off = 0;     // flow_head: second 1x1 conv
   int64_t wh_off = -1;                // conv: the layer's conv_halo_kernel weight copy (-1: none)
   int64_t ws_off = -1;                // conv: the layer's bf16x6 weight copy
+  int ksplit = 1;                     // conv (conv_buf_kernel): split-K factor, partial sums at part_off (film_kernels.h)
+  int64_t part_off = 0;
   int fold = 0, py = 0, px = 0;       // conv: sub-pixel phase of a folded upsample + 2x2 conv (H, W = low-res grid)
   int ftaps = 0; int tdy[4] = {0, 0, 0, 0}, tdx[4] = {0, 0, 0, 0};
   int64_t fold_woff[4] = {0, 0, 0, 0};  // fold == 2: weight offset of phase q relative to w_off
@@ -158,6 +160,7 @@ struct film_handle {
   uint64_t tick = 0;
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd F(2,3) kernel where measured faster (default), 2: every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
@@ -457,6 +460,20 @@ struct Planner {
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
+    // Split-K for the deep layers of the coarse levels: the whole K loop (up to 1377 steps) of such a layer otherwise runs
+    // on a handful of workgroups and IS the latency of the level (0.39 ms per flow-predictor conv_0 at 16 pixels).  The
+    // factor depends on the per-image pixel count and the layer only - never on the batch - so results stay independent
+    // of the batch size; partial sums are added in split order (no atomics).
+    if (h->opt_splitk && !op.halo && !op.split && !op.wino && !op.c3 && L.kmajor() && px <= 1024) {
+      const int nsteps = L.kh * L.kw * ctot / 16;
+      int S = nsteps < 128 ? 1 : px <= 64 ? 16 : px <= 256 ? 8 : 4;   // shallow layers: the extra launch costs more
+      while (S > 1 && nsteps / S < 32) S >>= 1;
+      if (S > 1 && L.cout % 4 == 0) {
+        op.ksplit = S;
+        const int sb = add_scratch("splitk:" + op.tag, (int64_t)S * M * L.cout);
+        op.part_off = P->bufs[sb].off;
+      }
+    }
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
     P->ops.push_back(op);
@@ -688,6 +705,7 @@ struct Planner {
     }
     conv_pw("fusion_out", "fusion/output_conv", net, view(out, 0, 0, 3), (int64_t)B * H * W, false);
     if (bad) return fail(h, FILM_ERR_INVALID, "%s", bad_msg.c_str());
+    P->arena_floats = cursor;   // the split-K partial-sum regions are added while the ops are emitted
     analyze_lanes();
     return FILM_OK;
   }
@@ -756,6 +774,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.NB = op.NB; p.H = op.H; p.W = op.W; p.Cout = op.Cout; p.Ctot = op.Ctot; p.leaky = op.leaky;
       p.M = op.NB * op.H * op.W;
       p.fold = op.fold; p.py = op.py; p.px = op.px; p.ftaps = op.ftaps;
+      p.ksplit = op.ksplit; p.part = op.ksplit > 1 ? arena + op.part_off : nullptr;
       for (int q = 0; q < 4; ++q) { p.tdy[q] = (signed char)op.tdy[q]; p.tdx[q] = (signed char)op.tdx[q]; p.fold_woff[q] = op.fold_woff[q]; }
       return film_launch_conv(p, op.tile, s);
     }
@@ -875,7 +894,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << ':' << op.ksplit;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -1027,7 +1046,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"py\":" << op.py
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
@@ -1353,6 +1372,15 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
   else if (!strcmp(key, "tune_ms")) h->opt_tune_ms = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "splitk")) {
+    if ((value != 0) != (h->opt_splitk != 0)) {  // plans carry the op list: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_splitk = value != 0;
+    }
+  }
   else if (!strcmp(key, "fold2x2")) {
     if ((value != 0) != (h->opt_fold != 0)) {  // plans carry the op list: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }

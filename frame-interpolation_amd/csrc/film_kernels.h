@@ -48,6 +48,13 @@ struct ConvParams {
   int fold, py, px, ftaps;
   signed char tdy[4], tdx[4];
   long long fold_woff[4];
+  // Split-K (conv_buf_kernel, fold == 0): ksplit > 1 -> blockIdx.z = split s sums the K steps
+  // [s * nsteps / ksplit, (s + 1) * nsteps / ksplit) and writes the raw partial sums to part[s][M][Cout]; film_launch_conv
+  // then adds the partials in split order, the bias and the activation (conv_splitk_reduce_kernel).  No atomics: the
+  // result is a fixed function of (shape, ksplit).  For the deep, small-M layers of the coarse pyramid levels, whose
+  // K loop (up to 1080 steps) otherwise runs on a handful of workgroups.
+  int ksplit;
+  float* part;
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,

@@ -193,6 +193,30 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
         eng.set_option('precision', 3)
 
 
+def test_every_buffer_lies_inside_the_arena_and_split_k_is_batch_independent():
+    """Workspace layout: buffers (including the split-K partial-sum regions added while the ops are emitted) are
+    disjoint and inside arena_floats; the split-K factor of a layer depends on the level size and the layer, not on
+    the batch (results must not depend on the batch size)."""
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED
+    eng = FilmEngine(PUBLISHED, device=-1)
+    splits = []
+    for b in (1, 3):
+        plan = eng.plan(b, 128, 192)
+        spans = sorted((bf['off'], bf['off'] + bf['floats']) for bf in plan['buffers'])
+        assert all(a[1] <= c[0] for a, c in zip(spans, spans[1:])), 'overlapping buffers'
+        assert spans[-1][1] <= plan['arena_floats']
+        names = {bf['name'] for bf in plan['buffers']}
+        ks = {op['tag']: op['ksplit'] for op in plan['ops'] if op['kind'] == 'conv_mfma'}
+        assert any(k > 1 for k in ks.values())
+        for tag, k in ks.items():
+            assert (k > 1) == (('splitk:' + tag) in names)
+        splits.append(ks)
+    assert splits[0] == splits[1]
+    eng.set_option('splitk', 0)
+    assert all(op['ksplit'] == 1 for op in eng.plan(1, 128, 192)['ops'] if op['kind'] == 'conv_mfma')
+
+
 def test_plan_shape_errors(tiny_weights):
     from film_hip.engine import FilmEngine, FilmError, FILM_ERR_INVALID
     from film_hip.options import TINY
