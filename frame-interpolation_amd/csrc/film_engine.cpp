@@ -464,9 +464,10 @@ struct Planner {
     // on a handful of workgroups and IS the latency of the level (0.39 ms per flow-predictor conv_0 at 16 pixels).  The
     // factor depends on the per-image pixel count and the layer only - never on the batch - so results stay independent
     // of the batch size; partial sums are added in split order (no atomics).
-    if (h->opt_splitk && !op.halo && !op.split && !op.wino && !op.c3 && L.kmajor() && px <= 1024) {
+    if (h->opt_splitk && !op.halo && !op.split && !op.wino && !op.c3 && L.kmajor() && px <= 4096) {
       const int nsteps = L.kh * L.kw * ctot / 16;
-      int S = nsteps < 128 ? 1 : px <= 64 ? 16 : px <= 256 ? 8 : 4;   // shallow layers: the extra launch costs more
+      // shallow layers: the extra launch costs more than it saves
+      int S = nsteps < 128 ? 1 : px <= 64 ? 16 : px <= 256 ? 8 : px <= 1024 ? 4 : nsteps >= 256 ? 2 : 1;
       while (S > 1 && nsteps / S < 32) S >>= 1;
       if (S > 1 && L.cout % 4 == 0) {
         op.ksplit = S;

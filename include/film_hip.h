@@ -133,8 +133,8 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
  *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
  *                  (default 1); ordering between the two comes from a buffer-overlap analysis of the plan
- *   "splitk"  0/1  1 (default): the deep convolutions of pyramid levels with <= 1024 pixels per image run split-K
- *                  (4-16 partial sums over K ranges, added in split order by a second kernel: deterministic, and the
+ *   "splitk"  0/1  1 (default): the deep convolutions of pyramid levels with <= 4096 pixels per image run split-K
+ *                  (2-16 partial sums over K ranges, added in split order by a second kernel: deterministic, and the
  *                  factor depends on the level size and the layer only, never on the batch); it is what bounds the
  *                  latency of small frames.  Changing it drops the cached plans.
  *   "fold2x2" 0/1  1 (default): the decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) runs as four
