@@ -215,7 +215,7 @@ def main():
                 continue
             f = o['flops']
             if o['tile'] & 256:
-                f *= 2.0 / 3.0
+                f *= 0.5 if o['tile'] & 2048 else 2.0 / 3.0    # Winograd F(4,3) / F(2,3) along x
             elif o['tag'].endswith(':phases'):
                 f *= 9.0 / 16.0
             exec_flops += f
@@ -233,8 +233,8 @@ def main():
         peak = {0: PEAK_FP32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS / 6, 2: PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
         roofline = {
             'bound': 'mfma',
-            'kernel': ('conv class = conv_wino_kernel / conv_halo_kernel / conv_buf_kernel (fp32 v_mfma_f32_32x32x2_f32); '
-                       'FLOPs are the direct convolution\'s (SURVEY 8d) also where the Winograd F(2,3) kernel executes 1.5x fewer')
+            'kernel': ('conv class = conv_wino43_kernel / conv_wino_kernel / conv_halo_kernel / conv_buf_kernel (fp32 v_mfma_f32_32x32x2_f32); '
+                       'FLOPs are the direct convolution\'s (SURVEY 8d) also where the Winograd F(4,3) / F(2,3) kernels execute 2x / 1.5x fewer')
                       if not args.precision else
                       ('conv class in the opt-in split mode = conv_winox3_kernel / conv_halo_split_kernel '
                        '(v_mfma_f32_32x32x16_bf16, fp32 accumulate) + the fp32 kernels on the small / 2x2 layers; '
@@ -249,7 +249,7 @@ def main():
             'all_conv_flops_per_step': alg_flops,
             'share_of_kernel_time': round(conv['ms'] / total_ms, 4),
             'executed': {'achieved': round(exec_tflops, 3), 'frac': round(exec_tflops / peak, 4),
-                         'note': 'FLOPs the matrix pipe executes (Winograd layers x2/3, folded 2x2 layers x9/16); `achieved` / '
+                         'note': 'FLOPs the matrix pipe executes (Winograd F(4,3) layers x1/2, F(2,3) x2/3, folded 2x2 layers x9/16); `achieved` / '
                                  '`frac` above count the direct convolution (SURVEY 8d) and can exceed the fp32 MFMA peak'},
         }
         extra = {}

@@ -27,6 +27,7 @@
 #include "conv_halo_impl.h"
 #include "conv_split_impl.h"
 #include "conv_wino_impl.h"
+#include "conv_wino43_impl.h"
 #include "conv_winox3_impl.h"
 #include "conv_foldx3_impl.h"
 #include "conv_igemm_impl.h"
@@ -99,6 +100,16 @@ static hipError_t launch_wino(const ConvParams& p, int shape, hipStream_t s) {
 }
 
 template <int F>
+static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case W43_4x64_T21: return conv_wino43_launch<4, 64, 2, 1, F>(p, s);
+    case W43_4x64_T12: return conv_wino43_launch<4, 64, 1, 2, F>(p, s);
+    case W43_4x32_T11: return conv_wino43_launch<4, 32, 1, 1, F>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int F>
 static hipError_t launch_winox3(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
     case WX3_4x128_T22: return conv_winox3_launch<4, 128, 2, 2, F>(p, s);
@@ -153,6 +164,7 @@ hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   if (tile & CONV_TILE_WINO) {
     if (p.ksize != 3) return hipErrorInvalidValue;
     if (tile & CONV_TILE_X3) return (tile & CONV_TILE_XCD) ? launch_winox3<CONV_B_XCD_M>(p, shape, s) : launch_winox3<0>(p, shape, s);
+    if (tile & CONV_TILE_F43) return (tile & CONV_TILE_XCD) ? launch_wino43<CONV_B_XCD_M>(p, shape, s) : launch_wino43<0>(p, shape, s);
     return (tile & CONV_TILE_XCD) ? launch_wino<CONV_B_XCD_M>(p, shape, s) : launch_wino<0>(p, shape, s);
   }
   if (tile & CONV_TILE_SPLIT) {

@@ -1,0 +1,310 @@
+// conv_wino43_impl.h -- 3x3 Conv2D('same') + bias + leaky_relu with the 1-D Winograd transform F(4,3) along x, fp32
+// MFMA: per FOUR output pixels of a row 6 x 3 (nu, dy) matrix steps per K chunk instead of 36 (direct) or 24 (F(2,3),
+// conv_wino_impl.h) - 2x / 1.33x fewer v_mfma_f32_32x32x2_f32.  The fp32 matrix pipe is power limited on this part
+// (every large layer of the fp32 path lands at 105-128 TFLOP/s executed whatever the kernel), so fewer
+// multiplies per output is what is left to buy time with.
+//
+// For an output row y and the pixel quad x = 4t .. 4t+3 with inputs d0..d5 = in[.][4t-1 .. 4t+4] (Lavin & Gray's
+// F(4,3), points 0, +-1, +-2, inf):
+//     v0 = 4 d0 - 5 d2 + d4            u0 = g0 / 4                          y0 = m0 + m1 + m2 + m3 + m4
+//     v1 = (d4 - 4 d2) + (d3 - 4 d1)   u1 = -(g0 + g1 + g2) / 6             y1 = (m1 - m2) + 2 (m3 - m4)
+//     v2 = (d4 - 4 d2) - (d3 - 4 d1)   u2 = -(g0 - g1 + g2) / 6             y2 = (m1 + m2) + 4 (m3 + m4)
+//     v3 = (d4 - d2) + 2 (d3 - d1)     u3 = g0 / 24 + g1 / 12 + g2 / 6      y3 = (m1 - m2) + 8 (m3 - m4) + m5
+//     v4 = (d4 - d2) - 2 (d3 - d1)     u4 = g0 / 24 - g1 / 12 + g2 / 6
+//     v5 = 4 d1 - 5 d3 + d5            u5 = g2                              m_nu = sum_dy sum_c v_nu * u_nu
+// fp32 throughout; on a K = 4608 test sum the rounding error is 3.9e-6 relative (F(2,3): 8.6e-7, direct: 6.4e-7).
+//
+//   * a workgroup owns TH rows x 128 pixels (32 quads = one 32-row MFMA tile per row) x BN output channels;
+//   * K chunks of 8 channels; the (TH+2) halo rows of a chunk are transformed ONCE on the way into LDS, image
+//     [halo row][nu 6][quad 32][8 channels] (32-byte rows, K-halves swapped on bit 3 of the row: conflict-free b128);
+//   * the six nu planes are independent GEMMs: wave half h accumulates nu = 3h .. 3h+2 for its TM rows x TN channel tiles
+//     (TM*TN*3 accumulator tiles per wave) and the halves swap partial output sums through LDS in the epilogue;
+//   * weights [Cout][chunk][dy][nu][8] (192 contiguous bytes per dy stage and channel) through a 3-slot LDS ring
+//     (slot = dy), requested three stages ahead in registers; one barrier per dy stage = 3*4*TM*TN MFMAs per wave;
+//   * fragment registers triple buffered over the nu steps: the ds_reads of step s+1 are issued before the MFMAs of s.
+#pragma once
+#include "conv_buf_impl.h"
+
+template <int TH, int BN, int TM, int TN, int FLAGS>
+__global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino43_kernel(ConvParams p) {
+  constexpr int RG = TH / TM, NG = BN / (32 * TN), PW = RG * NG, NW = 2 * PW, NT = NW * 64;
+  constexpr int HR = TH + 2;
+  constexpr int A_STAGE = HR * 6 * 32 * 8;     // floats: [hy][nu][quad][8]
+  constexpr int B_PLANE = BN * 8;              // floats of one nu plane of a stage
+  constexpr int B_STAGE = 6 * B_PLANE;
+  constexpr int ITEMS = HR * 32 * 2;           // (halo row, quad, 4-channel group)
+  constexpr int BU = BN * 12;                  // float4 units of one weight stage
+  constexpr int BLD = (BU + NT - 1) / NT;
+  static_assert(TH % TM == 0 && BN % (32 * TN) == 0 && ITEMS <= NT && 2 * ITEMS > NT, "bad tile");
+  static_assert(2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + 3 * B_STAGE, "exchange buffer does not fit");
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+
+  extern __shared__ __attribute__((aligned(1024))) float smem[];  // [A0][A1][B ring x3]
+  float* const Bsm = smem + 2 * A_STAGE;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int h = wv / PW, pw = wv % PW;     // nu half, pair-wave
+  const int rg = pw / NG, ng = pw % NG;
+
+  int bx = blockIdx.x, by = blockIdx.y;
+  if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int nwg = nbx * nby;
+    const int lin = by * nbx + bx;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int nl = base + idx;
+    bx = nl / nby;
+    by = nl - bx * nby;
+  }
+  const int ntx = (p.W + 127) >> 7, nty = (p.H + TH - 1) / TH;
+  const int img = bx / (ntx * nty);
+  const int trem = bx - img * (ntx * nty);
+  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * 128;
+  const int n0 = by * BN;
+
+  // ---- the A staging item of this thread: (halo row hy, quad tq, channel group q); threads past the last item repeat
+  // one (same values to the same LDS address) so that the staging code has no divergent branch -------------------------
+  int f = t;
+  if (f >= ITEMS) f -= ITEMS;
+  const int aq = f & 1, tq = (f >> 1) & 31, ahy = f >> 6;
+  const int a_y = y0 - 1 + ahy, a_x = x0 - 1 + 4 * tq;
+  unsigned a_ok = 0;          // bit j: pixel a_x + j is inside the image (and the row is)
+  if (a_y >= 0 && a_y < p.H)
+    for (int j = 0; j < 6; ++j)
+      if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
+  const int a_lds = ((ahy * 6) * 32 + tq) * 8 + ((aq ^ ((tq >> 3) & 1)) << 2);   // float index of nu = 0
+  const int scol = aq * 4;
+  unsigned a_off = 0, a_pix = 0;
+  conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
+  int sg = 0, c0 = 0, segC = p.seg[0].C;
+  auto setup_seg = [&]() {
+    const ConvSeg& s = p.seg[sg];
+    arsrc = conv_make_rsrc(s.ptr);
+    segC = s.C;
+    a_pix = (unsigned)s.stride * 4u;
+    int be = img + s.boff;
+    if (s.bmod && be >= s.bmod) be -= s.bmod;
+    // may point outside the tensor: only dereferenced under a_ok
+    a_off = (unsigned)(((long long)((size_t)be * p.H + a_y) * p.W + a_x) * s.stride + scol) * 4u;
+  };
+
+  // ---- B staging ---------------------------------------------------------------------------------------------------
+  const int nkc = p.Ctot / 8;
+  const int nstage = nkc * 3;    // (chunk, dy)
+  const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
+  unsigned boff[BLD];
+  int blds[BLD];
+#pragma unroll
+  for (int i = 0; i < BLD; ++i) {
+    const int u = t + NT * i;
+    const bool slot = u < BU;
+    const int kb = u & 1, row = slot ? (u >> 1) % BN : 0, nu = slot ? (u >> 1) / BN : 0;
+    boff[i] = (unsigned)((size_t)(n0 + row) * nstage * 192 + nu * 32 + kb * 16);
+    blds[i] = slot ? nu * B_PLANE + row * 8 + ((kb ^ ((row >> 3) & 1)) << 2) : -1;
+  }
+
+  bf4 araw[6];
+  bf4 breg[3][BLD];   // weights in flight: requested in stage s for stage s+3, written to the ring in stage s+1
+  bool chunk_ok = true;
+  auto load_item = [&]() {
+    const unsigned so = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const bool ok = chunk_ok && ((a_ok >> j) & 1u);
+      araw[j] = conv_buf_load(arsrc, ok ? a_off + (unsigned)j * a_pix : OOB, so);
+    }
+  };
+  auto store_item = [&](int stage) {
+    float* As = smem + stage * A_STAGE + a_lds;
+    bf4 v[6];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d0 = araw[0][c], d1 = araw[1][c], d2 = araw[2][c], d3 = araw[3][c], d4 = araw[4][c], d5 = araw[5][c];
+      const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+      const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+      v[0][c] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+      v[1][c] = t1 + t2;
+      v[2][c] = t1 - t2;
+      v[3][c] = t3 + t4;
+      v[4][c] = t3 - t4;
+      v[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    }
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<bf4*>(As + nu * 256) = v[nu];   // nu planes: 32 rows x 8 floats apart
+  };
+  auto next_chunk = [&](int kc_next) {
+    if (kc_next >= nkc) { chunk_ok = false; return; }
+    c0 += 8;
+    if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
+  };
+  auto load_b = [&](int s, int buf) {
+    const unsigned so = (unsigned)(s < nstage ? s : nstage - 1) * 192u;
+#pragma unroll
+    for (int i = 0; i < BLD; ++i) breg[buf][i] = conv_buf_load(brsrc, boff[i], so);
+  };
+  auto store_b = [&](int ring, int buf) {
+    float* Bs = Bsm + ring * B_STAGE;
+#pragma unroll
+    for (int i = 0; i < BLD; ++i)
+      if (NT * (i + 1) <= BU || blds[i] >= 0) *reinterpret_cast<bf4*>(Bs + blds[i]) = breg[buf][i];
+  };
+
+  f32x16 acc[TM][3][TN];   // [row][nu - 3h][channel tile]
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][v][j][r] = 0.f;
+
+  // ---- fragment addresses in float4 units: row * 2 + (K-half ^ bit 3 of the row) -------------------------------------
+  const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
+  constexpr int A_STAGE4 = A_STAGE / 4, B_STAGE4 = B_STAGE / 4, B_PLANE4 = B_PLANE / 4;
+  const int wy = rg * TM;
+  const int swb = (l31 >> 3) & 1;
+  const int a_ad = ((wy * 6 + 3 * h) * 32 + l31) * 2 + (half ^ swb);     // + ((mt + dy) * 6 + j) * 64, stage
+  const int b_ad = 2 * A_STAGE4 + (3 * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
+  int a_cur = a_ad;
+
+  bf4 fa[3][TM], fb[3][TN];   // [nu step j][tile]
+  auto fetch = [&](auto dy_c, auto j_c, int a_base) {
+    constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
+#pragma unroll
+    for (int mt = 0; mt < TM; ++mt) fa[J][mt] = smem4[a_base + ((mt + DY) * 6 + J) * 64];
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt) fb[J][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
+  };
+  auto compute = [&](auto j_c) {
+    constexpr int J = decltype(j_c)::value;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+          acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J][mt][k], fb[J][nt][k], acc[mt][J][nt], 0, 0, 0);
+  };
+
+  // ---- pipeline ----------------------------------------------------------------------------------------------------------
+  setup_seg();
+  load_item();
+  store_item(0);
+  load_b(0, 0);
+  store_b(0, 0);
+  load_b(1, 0);
+  store_b(1, 0);
+  load_b(2, 2);
+  next_chunk(1);
+  __syncthreads();
+  fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur);
+  int a_stage = 0;
+  for (int kc = 0; kc < nkc; ++kc) {
+    const int s0 = kc * 3;
+    const int a_next = a_ad + (a_stage ^ 1) * A_STAGE4;
+    auto stage = [&](auto dy_c) {
+      constexpr int DY = decltype(dy_c)::value;
+      load_b(s0 + DY + 3, DY);
+      if constexpr (DY == 0) load_item();
+      fetch(dy_c, std::integral_constant<int, 1>{}, a_cur);
+      compute(std::integral_constant<int, 0>{});
+      fetch(dy_c, std::integral_constant<int, 2>{}, a_cur);
+      compute(std::integral_constant<int, 1>{});
+      fetch(std::integral_constant<int, (DY + 1) % 3>{}, std::integral_constant<int, 0>{}, DY == 2 ? a_next : a_cur);
+      compute(std::integral_constant<int, 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      store_b((DY + 2) % 3, (DY + 2) % 3);
+      if constexpr (DY == 1) store_item(a_stage ^ 1);
+      __syncthreads();
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    next_chunk(kc + 2);
+    a_stage ^= 1;
+    a_cur = a_next;
+  }
+
+  // ---- epilogue: y0 = (m0+m1+m2) + (m3+m4), y1 = (m1-m2) + 2(m3-m4) on half 0; y2 = (m1+m2) + 4(m3+m4),
+  // y3 = (m1-m2) + (8(m3-m4) + m5) on half 1.  The halves swap the bracketed sums they lack through LDS (the staging
+  // buffers are free after the last barrier), one tile per round.  C/D layout of the 32x32 MFMA: col = lane&31 (cout),
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5) = quad.
+  float* const xbuf = smem;
+  constexpr int XW = TM * TN * 16 * 64;   // floats one wave gives per round
+  auto finish = [&](auto h_c) {
+    constexpr int H = decltype(h_c)::value;
+    float* const give = xbuf + (H * PW + pw) * XW + lane;
+    const float* const take = xbuf + ((1 - H) * PW + pw) * XW + lane;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+      if (round) __syncthreads();   // everybody has consumed round 0
+#pragma unroll
+      for (int mt = 0; mt < TM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float ma = acc[mt][1][nt][r], mb = acc[mt][2][nt][r];      // H = 0: m1, m2;  H = 1: m4, m5
+            const float m0 = acc[mt][0][nt][r];                                //        m0           m3
+            float g;
+            if (H == 0) g = round == 0 ? ma + mb : ma - mb;                    // (m1 + m2) / (m1 - m2)
+            else g = round == 0 ? m0 + ma : 2.f * (m0 - ma);                   // (m3 + m4) / 2 (m3 - m4)
+            give[((mt * TN + nt) * 16 + r) * 64] = g;
+          }
+      __syncthreads();
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) {
+        const int n = n0 + (ng * TN + nt) * 32 + l31;
+        const float bv = p.bias[n];
+#pragma unroll
+        for (int mt = 0; mt < TM; ++mt) {
+          const int y = y0 + wy + mt;
+          if (y >= p.H) continue;
+          const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int x = x0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * half) + 2 * H + round;
+            const float got = take[((mt * TN + nt) * 16 + r) * 64];
+            const float ma = acc[mt][1][nt][r], mb = acc[mt][2][nt][r], m0 = acc[mt][0][nt][r];
+            float v;
+            if (H == 0) v = round == 0 ? ((m0 + ma) + mb) + got : (ma - mb) + got;                       // y0, y1
+            else v = round == 0 ? got + 4.f * (m0 + ma) : got + (8.f * (m0 - ma) + mb);                  // y2, y3
+            v += bv;
+            if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+            if (x < p.W) p.out[(rowbase + x) * p.ostride + n] = v;
+          }
+        }
+      }
+    }
+  };
+  if (h == 0) finish(std::integral_constant<int, 0>{});
+  else finish(std::integral_constant<int, 1>{});
+}
+
+template <int TH, int BN, int TM, int TN, int FLAGS>
+hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
+  constexpr size_t lds = (2 * (size_t)(TH + 2) * 6 * 32 * 8 + 3 * 6 * (size_t)BN * 8) * sizeof(float);
+  constexpr int NT = (TH / TM) * (BN / (32 * TN)) * 128;
+  static_assert(lds <= 160 * 1024, "LDS");
+  auto kern = conv_wino43_kernel<TH, BN, TM, TN, FLAGS>;
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
+  const int ntx = (p.W + 127) / 128, nty = (p.H + TH - 1) / TH;
+  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
+  return hipGetLastError();
+}

@@ -74,6 +74,7 @@ struct OpDesc {
   int64_t fold_woff[4] = {0, 0, 0, 0};  // fold == 2: weight offset of phase q relative to w_off
   int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
   int64_t wx_off = -1;                // conv: ... and its 2-plane bf16 split (precision mode bf16x3, conv_winox3_kernel)
+  int64_t w43_off = -1;               // conv: the layer's Winograd F(4,3) weight copy (conv_wino43_kernel)
   int64_t wfx_off = -1;               // conv: phase-summed weights of a folded 2x2 layer as bf16 hi / mid (conv_foldx3_kernel)
   int wino = 0;                       // conv: 1 = runs on conv_wino_kernel, 2 = on conv_winox3_kernel (precision bf16x3)
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
@@ -105,6 +106,7 @@ struct LayerPack {
   int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/8][12][8]
   int64_t wfx_off = -1;      // 2x2 layers after an upsample: the phase-summed weights as bf16 hi / mid for conv_foldx3_kernel,
                              //     [Cout][ctot/16][9 (tap, phase) steps][plane][16] bf16
+  int64_t w43_off = -1;      // ... the F(4,3)-along-x transformed copy for conv_wino43_kernel, [Cout][ctot/8][3 dy][6 nu][8]
   int64_t wx_off = -1;       // ... and the transformed copy split into bf16 hi / mid for conv_winox3_kernel,
                              //     [Cout][ctot/16][dy][j][h][plane][16] bf16 (nu = 2h + j)
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
@@ -162,7 +164,7 @@ struct film_handle {
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
-  int opt_wino = 1;       // 0: never, 1: Winograd F(2,3) kernel where measured faster (default), 2: every eligible 3x3 conv
+  int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
   int opt_tune_ms = 0;    // autotune: minimum kernel time spent per candidate (0: two launches)
   int opt_lanes = 1;      // 1: replay graphs use a second (side) stream for independent small / HBM-bound work
@@ -325,6 +327,8 @@ void build_layers(film_t* h) {
       L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12;
       off = (off + 3) & ~int64_t(3);
       L.wx_off = off; off += L.packed_rows() * L.cout / 9 * 12;
+      off = (off + 3) & ~int64_t(3);
+      L.w43_off = off; off += L.packed_rows() * L.cout / 9 * 18;
     }
     off = (off + 3) & ~int64_t(3);
   }
@@ -398,7 +402,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off; op.w43_off = L.w43_off;
     if (h->opt_fold && L.wf_off >= 0 && op.nseg == 1 && segs[0].up && !(H & 1) && !(W & 1)) {
       // nearest x2 + 2x2 'same' conv == four phase convolutions on the low-resolution input: kernel tap (dy, dx) of
       // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
@@ -446,17 +450,22 @@ struct Planner {
     // In precision mode bf16x3 the same layers run the Winograd form of the split kernel (conv_winox3_kernel).
     op.wino = op.split != 1 && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
               ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
-               px >= 100000 || h->opt_wino == 2);
-    if (op.wino && h->opt_precision == 2 && (op.split == 2 || h->opt_wino == 2)) {
+               px >= 100000 || h->opt_wino >= 2);
+    if (op.wino && h->opt_precision == 2 && (op.split == 2 || h->opt_wino >= 2)) {
       // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  The Winograd form wins with the 2 x 2 wave block of
       // its 128-channel tile (0.88-0.94x the time of conv_halo_split_kernel<..,3> per layer, 427 vs 367 TFLOP/s at
       // K = 22 032) and loses with the 64-channel tiles (1.08-1.30x: twice the A staging per MFMA) - per-op profiles of
       // the two plans and tools/conv_bench.hip agree.
-      if (L.cout % 128 == 0 || h->opt_wino == 2) op.split = 0, op.wino = 2;
+      if (L.cout % 128 == 0 || h->opt_wino >= 2) op.split = 0, op.wino = 2;
       else if (op.split == 2) op.wino = 0;
     }
+    // fp32: F(4,3) along x (conv_wino43_kernel, 2x fewer MFMAs than direct where F(2,3) has 1.5x) on the levels whose width
+    // fills its 128-pixel patches (at most 15 % of the last patch of a row empty); wino = 3.  "winograd" = 2 / 3 force
+    // F(2,3) / F(4,3) onto every eligible layer (tests).
+    if (op.wino == 1 && h->opt_wino != 2 && L.w43_off >= 0 && (h->opt_wino == 3 || 128 * ((W + 127) / 128) * 100 <= 115 * W)) op.wino = 3;
     if (op.split || op.wino) op.halo = 0;
-    op.tile = op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
+    op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_4x64_T21 : W43_4x32_T11) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
+              : op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
               : op.halo ? choose_halo_tile(L.cout) : choose_tile(M, L.cout);
@@ -768,7 +777,8 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
       p.ksize = op.ksize;
-      p.w = wts + ((op.tile & CONV_TILE_FOLDX3) ? op.wfx_off : (op.tile & CONV_TILE_WINO) ? ((op.tile & CONV_TILE_X3) ? op.wx_off : op.ww_off) : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
+      p.w = wts + ((op.tile & CONV_TILE_FOLDX3) ? op.wfx_off
+                   : (op.tile & CONV_TILE_WINO) ? ((op.tile & CONV_TILE_X3) ? op.wx_off : (op.tile & CONV_TILE_F43) ? op.w43_off : op.ww_off) : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
                    : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
       p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride;
@@ -861,6 +871,13 @@ std::vector<int> wino_candidates(int Cout) {
   return out;
 }
 
+std::vector<int> wino43_candidates(int Cout) {
+  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_4x64_T12, W43_4x32_T11} : std::vector<int>{W43_4x32_T11};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> foldx3_candidates(int Cout) {
   std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{FX3_4x64, FX3_8x64, FX3_4x128} : std::vector<int>{FX3_4x64, FX3_8x64};
   std::vector<int> out;
@@ -921,7 +938,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -1047,7 +1064,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"w43_off\":" << op.w43_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
@@ -1288,6 +1305,7 @@ int film_finalize(film_t* h) {
                             // 8-channel chunks: [Cout][chunk8][nu*3+dy][8]
         float* dw = h->packed_host.data() + L.ww_off;
         uint16_t* dx3 = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.wx_off);
+        float* d43 = h->packed_host.data() + L.w43_off;
         const size_t nk8 = (size_t)ct / 8, nk16 = (size_t)ct / 16;
         for (int dy = 0; dy < 3; ++dy)
           for (size_t kc = 0; kc < nk8; ++kc) {
@@ -1303,6 +1321,20 @@ int film_finalize(film_t* h) {
                 const float g0 = rows[0][j] ? rows[0][j][co] : 0.f, g1 = rows[1][j] ? rows[1][j][co] : 0.f,
                             g2 = rows[2][j] ? rows[2][j][co] : 0.f;
                 u[0][j] = g0; u[1][j] = ((g0 + g2) + g1) * 0.5f; u[2][j] = ((g0 + g2) - g1) * 0.5f; u[3][j] = g2;
+              }
+              {  // F(4,3) along x (conv_wino43_impl.h): [Cout][chunk8][dy][nu 6][8]
+                float* d = d43 + ((((size_t)co * nk8 + kc) * 3 + dy) * 6) * 8;
+                for (int j = 0; j < 8; ++j) {
+                  const float g0 = rows[0][j] ? rows[0][j][co] : 0.f, g1 = rows[1][j] ? rows[1][j][co] : 0.f,
+                              g2 = rows[2][j] ? rows[2][j][co] : 0.f;
+                  const float e = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), o = g1 * (1.f / 12.f);
+                  d[0 * 8 + j] = g0 * 0.25f;
+                  d[1 * 8 + j] = -((g0 + g2) + g1) * (1.f / 6.f);
+                  d[2 * 8 + j] = -((g0 + g2) - g1) * (1.f / 6.f);
+                  d[3 * 8 + j] = e + o;
+                  d[4 * 8 + j] = e - o;
+                  d[5 * 8 + j] = g2;
+                }
               }
               for (int nu = 0; nu < 4; ++nu) {
                 memcpy(dw + (((size_t)co * nk8 + kc) * 12 + nu * 3 + dy) * 8, u[nu], sizeof(u[nu]));
@@ -1392,7 +1424,7 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "winograd")) {
-    if (value < 0 || value > 2) return fail(h, FILM_ERR_INVALID, "winograd: 0, 1 or 2");
+    if (value < 0 || value > 3) return fail(h, FILM_ERR_INVALID, "winograd: 0, 1, 2 or 3");
     if ((int)value != h->opt_wino) {  // plans carry the kernel choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());

@@ -159,8 +159,12 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                 CONV_TILE_X3 = 512 /* precision mode bf16x3.  With CONV_TILE_SPLIT: conv_halo_split_kernel on planes hi, mid with
                                       three products; with CONV_TILE_WINO: conv_winox3_kernel, shape index = WinoX3Tile,
                                       weights [Cout][chunk][dy][j][h][plane][16] bf16 */,
+                CONV_TILE_F43 = 2048 /* with CONV_TILE_WINO: conv_wino43_kernel (F(4,3) along x, fp32): shape index = Wino43Tile,
+                                        weights [Cout][chunk of 8][dy][nu 6][8] */,
                 CONV_TILE_FOLDX3 = 1024 /* conv_foldx3_kernel (precision mode bf16x3, folded upsample + 2x2): shape index =
                                            FoldX3Tile, weights [Cout][chunk][9 (tap, phase) steps][plane][16] bf16 */ };
+// conv_wino43_kernel tiles (CONV_TILE_WINO | CONV_TILE_F43): patch rows x 128 pixels x output channels, wave block TM x TN
+enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2 };   // all 8 waves
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

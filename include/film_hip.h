@@ -141,10 +141,11 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  sub-pixel phase convolutions on the low-resolution input with pre-summed weights (9 taps per 4
  *                  outputs instead of 16; an exact regrouping of the sum, rounding differs at the 1e-7 level).
  *                  0: one 2x2 convolution with the upsample folded into its gather.  Drops the cached plans.
- *   "winograd" w   1 (default): 3x3 convolutions with Cout % 128 == 0 on the large pyramid levels use the 1-D
- *                  Winograd transform F(2,3) along x (1.5x fewer fp32 multiplies; fp32 throughout, the rounding
- *                  differs from the direct sum at the 1e-6 level).  0: direct kernels only.  2: every eligible
- *                  3x3 convolution (tests).  Changing it drops the cached plans.
+ *   "winograd" w   1 (default): the large 3x3 convolutions use a 1-D Winograd transform along x - F(4,3) (2x fewer
+ *                  fp32 multiplies, 128-pixel patches) on the levels whose width fills its patches, F(2,3) (1.5x fewer)
+ *                  elsewhere; fp32 throughout, the rounding differs from the direct sum at the 1e-6 (F(2,3)) /
+ *                  5e-6 (F(4,3)) level.  0: direct kernels only.  2 / 3: F(2,3) / F(4,3) on every eligible 3x3
+ *                  convolution (tests).  Changing it drops the cached plans.
  *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.

@@ -108,6 +108,15 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 half = np.float32(0.5)
                 want_u = np.stack([g0, ((g0 + g2) + g1) * half, ((g0 + g2) - g1) * half, g2])
                 assert np.array_equal(ww, want_u), 'Winograd weight copy differs'
+                if op.get('w43_off', -1) >= 0:
+                    # F(4,3) copy for conv_wino43_kernel: [Cout][chunk8][dy][nu 6][8], same float32 operation order as the packer
+                    w43 = packed[op['w43_off']:op['w43_off'] + 18 * ct * co].reshape(co, ct // 8, 3, 6, 8)
+                    w43 = w43.transpose(3, 2, 1, 4, 0).reshape(6, 3, ct, co)      # [nu][dy][c][n]
+                    f = np.float32
+                    c6, c12, c24 = f(1) / f(6), f(1) / f(12), f(1) / f(24)
+                    e, o = g0 * c24 + g2 * c6, g1 * c12
+                    want43 = np.stack([g0 * f(0.25), -((g0 + g2) + g1) * c6, -((g0 + g2) - g1) * c6, e + o, e - o, g2])
+                    assert np.array_equal(w43, want43), 'F(4,3) weight copy differs'
                 if op.get('wx_off', -1) >= 0:
                     # bf16x3 copy of the transformed weights: [Cout][chunk16][dy][j][h][plane][16] bf16, nu = 2h + j,
                     # hi + mid within 2^-17 of the fp32 value (nearest split)

@@ -332,6 +332,23 @@ def test_halo_kernels_on_every_level(published, precision, b, h, w):
     eng.close()
 
 
+@pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192), (1, 128, 320)])
+def test_winograd_f43_kernel_on_every_level(published, b, h, w):
+    """winograd = 3 forces conv_wino43_kernel (F(4,3) along x, 128-pixel patches) onto every eligible 3x3 convolution:
+    ragged patches (W < 128 down to 1 pixel, quads cut by the right edge, H not a multiple of 4), multi-segment inputs,
+    batch remaps - stage-by-stage parity with the oracle."""
+    from film_hip.engine import FilmEngine
+    opt, wts, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(wts)
+    eng.set_option('winograd', 3)
+    plan = eng.plan(b, h, w)
+    assert sum(1 for op in plan['ops'] if op.get('wino') == 3) > 30
+    x0, x1 = _pair(b, h, w, seed=59 + h + w)
+    _check_stages(eng, opt, wts, x0, x1)
+    eng.close()
+
+
 @pytest.mark.parametrize('precision', [0, 2])
 @pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192)])
 def test_winograd_kernel_on_every_level(published, precision, b, h, w):

@@ -163,12 +163,12 @@ def test_plan_interpreter_matches_oracle_published_64():
 
 def test_precision_modes_choose_kernel_families_by_shape_only():
     """The kernel family of a layer is a pure function of (layer shape, precision option) - never of batch size or
-    timing.  Mode 0: no split kernels; mode 1: conv_halo_split_kernel (split = 1); mode 2: conv_winox3_kernel
+    timing.  Mode 0: no split kernels, conv_wino43_kernel (wino = 3) / conv_wino_kernel (1) by level width; mode 1: conv_halo_split_kernel (split = 1); mode 2: conv_winox3_kernel
     (wino = 2) on the Cout % 128 == 0 layers, conv_halo_split_kernel<..,3> (split = 2) on the others, conv_foldx3_kernel
     (fold with split = 2) on the decoder's large upsample + 2x2 layers; tile ids carry the matching flags."""
     from film_hip.engine import FilmEngine, FilmError
     from film_hip.options import PUBLISHED
-    WINO, SPLIT, X3, FOLDX3 = 256, 128, 512, 1024
+    WINO, SPLIT, X3, FOLDX3, F43 = 256, 128, 512, 1024, 2048
     eng = FilmEngine(PUBLISHED, device=-1)
     fam = {}
     for mode in (0, 1, 2):
@@ -182,9 +182,10 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
                 assert bool(t & FOLDX3) == (op['fold'] == 2 and op['split'] == 2)
                 assert bool(t & WINO) == (op['wino'] != 0) and bool(t & SPLIT) == (op['split'] != 0 and not op['fold'])
                 assert bool(t & X3) == (op['wino'] == 2 or (op['split'] == 2 and not op['fold']))
+                assert bool(t & F43) == (op['wino'] == 3)
         assert per_batch[0] == per_batch[1]
         fam[mode] = per_batch[0]
-    assert all(s == 0 and w in (0, 1) for _, s, w, _ in fam[0])
+    assert all(s == 0 and w in (0, 1, 3) for _, s, w, _ in fam[0]) and any(w == 3 for _, _, w, _ in fam[0])
     assert any(s == 1 for _, s, _, _ in fam[1]) and all(w == 0 for _, s, w, _ in fam[1] if s)
     assert any(w == 2 for _, _, w, _ in fam[2]) and any(s == 2 and not f for _, s, _, f in fam[2])
     assert any(s == 2 and f == 2 for _, s, _, f in fam[2])

@@ -17,6 +17,7 @@
 #include "experiments/conv_dma_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_split_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_winox3_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_wino43_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino_impl.h"
 #include "experiments/conv_wino16_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
@@ -62,11 +63,13 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 #define W8(TH, BN, WM, WN) {"wino " #TH "x64x" #BN " w" #WM "x" #WN " f4", TH * 64, BN, 8, 5, conv_wino_launch<TH, BN, WM, WN, 4>}
 #define X(TH, BN, TM, TN) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f4", TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, 4>}
 #define XA(TH, BN, TM, TN, FL) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, FL>}
+#define F43(TH, BN, TM, TN) {"wino43 " #TH "x128x" #BN " t" #TM "x" #TN " f4", TH * 128, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, 4>}
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
     V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4),
     W(4, 128, 4, 2), W(4, 64, 4, 1), W(4, 64, 4, 2), W(2, 128, 2, 2), W(4, 32, 4, 1),
     W8(4, 64, 4, 2), W8(4, 128, 4, 2), W8(4, 128, 4, 4), W8(4, 32, 4, 1), W8(8, 64, 8, 2), W8(8, 32, 8, 1), W8(2, 64, 2, 2),
+    F43(4, 64, 1, 2), F43(4, 64, 2, 1), F43(4, 32, 1, 1),
     X(4, 128, 2, 2), XA(4, 128, 2, 2, 1028), XA(4, 128, 2, 2, 2052), XA(4, 64, 2, 1, 1028), XA(4, 64, 2, 1, 2052), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
     S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 128, 2, 2, 3), S(16, 128, 4, 2, 3), S(16, 64, 4, 1, 3), S(8, 64, 2, 1, 3), S(16, 128, 4, 1, 3), S(8, 64, 4, 1, 3), S(4, 128, 2, 2, 3), S(8, 32, 4, 1, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
@@ -152,6 +155,20 @@ __global__ void pack_winox3_kernel(const float* src, unsigned short* dst, int C,
   }
 }
 
+// [tap*C + c][N] -> [N][chunk8][dy][nu 6][8]: F(4,3) weight transform along x (conv_wino43_impl.h)
+__global__ void pack_wino43_kernel(const float* src, float* dst, int C, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)3 * C * N) return;
+  const int n = (int)(i % N);
+  const int c = (int)((i / N) % C), dy = (int)(i / ((size_t)N * C));
+  const float g0 = src[((size_t)(dy * 3 + 0) * C + c) * N + n], g1 = src[((size_t)(dy * 3 + 1) * C + c) * N + n],
+              g2 = src[((size_t)(dy * 3 + 2) * C + c) * N + n];
+  const float u[6] = {g0 * 0.25f, -((g0 + g2) + g1) * (1.f / 6.f), -((g0 + g2) - g1) * (1.f / 6.f),
+                      (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) + g1 * (1.f / 12.f), (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) - g1 * (1.f / 12.f), g2};
+  for (int nu = 0; nu < 6; ++nu)
+    dst[((((size_t)n * (C / 8) + c / 8) * 3 + dy) * 6 + nu) * 8 + c % 8] = u[nu];
+}
+
 __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(a[i] - b[i]));
@@ -197,6 +214,7 @@ int main(int argc, char** argv) {
     const size_t n_in = M * sh.C, n_w = (size_t)sh.ks * sh.ks * sh.C * sh.Cout, n_out = M * sh.Cout;
     float *d_in, *d_w, *d_wt, *d_wh, *d_ww, *d_w8, *d_b, *d_out, *d_zero, *d_ref, *d_md;
     unsigned short *d_ws, *d_wx;
+    float* d_w43;
     CK(hipMalloc(&d_in, n_in * 4));
     CK(hipMalloc(&d_w, n_w * 4));
     CK(hipMalloc(&d_wt, n_w * 4));
@@ -205,6 +223,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_ww, n_w * 4 * 12 / 9 + 64));
     CK(hipMalloc(&d_w8, n_w * 4 * 12 / 9 + 64));
     CK(hipMalloc(&d_wx, n_w * 4 * 12 / 9 + 64));
+    CK(hipMalloc(&d_w43, n_w * 4 * 18 / 9 + 64));
     CK(hipMalloc(&d_ref, n_out * 4));
     CK(hipMalloc(&d_md, 4));
     CK(hipMalloc(&d_zero, 256));
@@ -217,6 +236,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wt, sh.ks * sh.ks * sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_ww, sh.C, sh.Cout);
     if (sh.ks == 3 && sh.C % 16 == 0) hipLaunchKernelGGL(pack_winox3_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_wx, sh.C, sh.Cout);
+    if (sh.ks == 3) hipLaunchKernelGGL(pack_wino43_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_w43, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino8_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_w8, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_ws, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wh, sh.C, sh.Cout);
@@ -234,7 +254,7 @@ int main(int argc, char** argv) {
       if (only_variant && !strstr(v.name, only_variant)) continue;
       CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
       if (v.wkind >= 2 && sh.ks != 3) continue;
-      p.w = v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 4 ? d_ww : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
+      p.w = v.wkind == 7 ? d_w43 : v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 4 ? d_ww : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
       CK(v.fn(p, st));  // warm + correctness
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
       hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
@@ -266,7 +286,7 @@ int main(int argc, char** argv) {
              flops / best * 1e-9, rel < 1e-5 ? "ok" : "(ablation)", rel, maxdiff);
       fflush(stdout);
     }
-    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ww)); CK(hipFree(d_w8)); CK(hipFree(d_wx)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
+    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ww)); CK(hipFree(d_w8)); CK(hipFree(d_w43)); CK(hipFree(d_wx)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   return 0;
 }
