@@ -14,14 +14,14 @@ import re
 
 
 def short(name):
-    m = re.search(r'(conv_buf_kernel|conv_halo_kernel|conv_winox3_kernel|conv_wino_kernel|conv_foldx3_kernel|conv_splitk_reduce_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
+    m = re.search(r'(conv_buf_kernel|conv_halo_kernel|conv_winox3_kernel|conv_wino43_kernel|conv_wino_kernel|conv_foldx3_kernel|conv_splitk_reduce_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
                   r'pool_vec_kernel|pool_c3_kernel|flow_up_kernel|flow_add_kernel|pack_flow_kernel|frame_to_tiles_kernel|'
                   r'tiles_to_frame_kernel)', name)
     return m.group(1) if m else None
 
 
 def klass(k):
-    return 'conv_mfma' if k in ('conv_buf_kernel', 'conv_halo_kernel', 'conv_wino_kernel', 'conv_winox3_kernel', 'conv_foldx3_kernel', 'conv_splitk_reduce_kernel',
+    return 'conv_mfma' if k in ('conv_buf_kernel', 'conv_halo_kernel', 'conv_wino_kernel', 'conv_wino43_kernel', 'conv_winox3_kernel', 'conv_foldx3_kernel', 'conv_splitk_reduce_kernel',
                               'conv_halo_split_kernel', 'conv_igemm_kernel') else k.replace('_kernel', '')
 
 
@@ -106,7 +106,7 @@ def main():
     else:
         print('\n'.join(lines))
     if args.json and 'conv_mfma' in js:
-        out = {'source': f'{args.md or args.dir} ({args.command}, last forward)', 'kernel': 'conv class: conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf (+ split-K reduce) + first-layer conv_igemm_kernel',
+        out = {'source': f'{args.md or args.dir} ({args.command}, last forward)', 'kernel': 'conv class: conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf (+ split-K reduce) + first-layer conv_igemm_kernel',
                'fetch_correction': 2.0, 'classes': js, 'hbm_bytes_per_launch': js['conv_mfma'].get('hbm_bytes_per_launch'),
                'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters'}
         json.dump(out, open(args.json, 'w'), indent=1)
