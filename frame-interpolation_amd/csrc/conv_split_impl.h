@@ -4,7 +4,8 @@
 // 8 + 8 + 8 significant bits, the sum is EXACT - see conv_split4) and the product formed on
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate; bf16 x bf16 products are exact in fp32) from
 //   NPROD = 6:  hi*hi + (hi*mid + mid*hi) + (hi*lo + lo*hi + mid*mid)     dropped: mid*lo, lo*mid, lo*lo <= 2^-25 |ab|
-//   NPROD = 3:  hi*hi + (hi*mid + mid*hi)                                  dropped terms <= 3 * 2^-18 |ab|, zero mean
+//   NPROD = 3:  hi*hi + (hi*mid + mid*hi)                                  dropped: mid*mid <= 2^-16 |ab| plus two residues <= 2^-17 |ab|
+//                                                                         (worst case 2^-15; measured rms 4.4e-6, mean 1e-9: zero mean)
 // Six (three) bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16 K: 2.67x (5.3x) the matrix
 // rate.  bf16x6 is fp32-level accurate (max |delta| 2.8e-5 on outputs of O(10) against the fp32 kernels,
 // tools/conv_bench.hip: the same as between two fp32 kernels that sum K in a different order); bf16x3 stages only

@@ -127,8 +127,9 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  partial products >= 2^-16 in fp32 on the bf16 matrix pipe (dropped terms < 2^-23 relative);
  *                  about 1.5x faster, results differ from mode 0 at the level of a changed summation order.
  *                  2: "bf16x3" - the same kernels with a nearest 2-way split (hi + mid, |x - hi - mid| <= 2^-17 |x|)
- *                  and the three products hi*hi + hi*mid + mid*hi: per-product error <= 3 * 2^-18 relative with
- *                  zero mean (not an fp32 result; well inside the 1e-3 image bound, see tests).
+ *                  and the three products hi*hi + hi*mid + mid*hi: per-product error <= 2^-15 relative in the worst
+ *                  case, 4.4e-6 rms, zero mean (not an fp32 result; 7e-6 from the oracle end to end against the 1e-3
+ *                  image bound, see tests).
  *                  Changing it drops the cached plans.
  *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
  *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
