@@ -13,12 +13,21 @@ frame pairs: no collective on the data path, weights are broadcast once over RCC
 ("scaling": "weak").
 
 Extra objects in the JSON line:
-  roofline     fp32-MFMA roofline of the dominant kernel class (conv_igemm): algorithmic conv FLOPs of
-               one forward / summed duration of its conv launches, measured with hipEvents around
-               every launch on the launch stream (engine profile mode), vs 157.3 TFLOP/s.
+  roofline     fp32-MFMA roofline of the dominant kernel class (the MFMA convolutions): FLOPs the matrix
+               pipe EXECUTES in one forward (the Winograd F(4,3) / F(2,3) kernels and the sub-pixel fold
+               execute 1/2, 2/3, 9/16 of the direct convolution's multiplies) / summed duration of its
+               launches, measured with hipEvents around every launch on the launch stream (engine
+               profile mode), vs 157.3 TFLOP/s -> `achieved`, `frac` (a utilisation, <= 1).
+               `direct_equivalent` prices the same time with SURVEY 8d's direct-convolution FLOP count
+               (can exceed the peak: that is the algorithmic saving, not utilisation).
   cpu_baseline the CPU oracle (PyTorch-CPU/oneDNN + numpy restatement of the TF graph, kind "port")
-               timed on this host's cores on a bounded sample (one 256x256 pair), converted to
-               1080p-tiled frames/s by the exact conv-FLOP ratio.
+               timed on this host's cores on ONE real 960x576 tile of the workload (a frame is four such
+               tiles run one after the other, as the reference's tile loop does): frames/s = 1 / (4 t).
+
+`--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N
+ranks (one per GPU, 127.0.0.1 rendezvous) and refuses to run when fewer than N GPUs are visible; `n_gpus` in
+the line is the number of ranks that actually reported.  `--plan-only` drives the same launcher / broadcast /
+sharding / timing-reduction code on CPU (gloo, plan-only engine handles, no compute) for the CPU tests.
 """
 import argparse
 import json
@@ -67,43 +76,122 @@ def synth_pair(h, w, seed):
 
 
 def cpu_baseline(weights):
-    """Times the oracle on the host cores: one 256x256 pair of the published net (0.278 TFLOP)."""
+    """Times the oracle on the host cores on ONE real tile of the headline workload: a 960x576 pair of the
+    published net (2.348 TFLOP of convolutions + the 22 gather warps), no scaling by FLOP ratios.  The
+    reference's tile loop runs the four tiles of a 1080p frame one after the other (eval/interpolator.py:
+    199-202), so a frame costs four tile times."""
     from oracle import film_oracle as fo
     ncores = os.cpu_count() or 1
-    # oneDNN with one thread per hardware thread thrashes on many-core hosts for these small convs
-    # (256 threads: 93 s for this sample); pick the best of a few thread counts on one mid-size layer.
-    probe_x = torch.randn(1, 256, 64, 64)
+    # oneDNN with one thread per hardware thread thrashes on many-core hosts; pick the best of a few
+    # thread counts on one mid-size layer of the tile (level 2: 240x144, 256 -> 256 channels).
+    probe_x = torch.randn(1, 256, 144, 240)
     probe_w = torch.randn(256, 256, 3, 3)
     best_t, best_dt = 1, float('inf')
     for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64, 128)}):
         torch.set_num_threads(nt)
         torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
         t0 = time.perf_counter()
-        for _ in range(3):
-            torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
+        torch.nn.functional.conv2d(probe_x, probe_w, padding=1)
         d = time.perf_counter() - t0
         if d < best_dt:
             best_t, best_dt = nt, d
     ncores = best_t
     torch.set_num_threads(ncores)
-    x0, x1 = synth_pair(256, 256, 1)
-    fo.film_forward(x0, x1, weights, fo.Options())   # warm-up (thread pools, oneDNN primitive cache)
+    xs, _ = synth_pair(64, 64, 1)
+    fo.film_forward(xs, xs, weights, fo.Options())    # warm-up of thread pools / primitive caches (64x64)
+    x0, x1 = synth_pair(576, 960, 2)
     reps, total = 0, 0.0
-    while total < 12.0 and reps < 64:                 # bounded sample: about 12 s of CPU work
+    while total < 10.0 and reps < 8:                  # bounded sample: one tile is about 10-20 s of CPU work
         t0 = time.perf_counter()
         fo.film_forward(x0, x1, weights, fo.Options())
         total += time.perf_counter() - t0
         reps += 1
     dt = total / reps
-    ratio = (256 * 256) / (4 * 576 * 960)  # conv FLOPs are exactly proportional to padded pixels
     return {
-        'value': round(ratio / dt, 6), 'unit': 'frames/s (1080p 2x2-tiled equivalent)', 'cores': ncores,
-        'kind': 'port',
-        'sample': f'{reps} x one 256x256 pair, published film_net, {dt:.2f} s each ({total:.1f} s in all) on {ncores} '
-                  f'threads (PyTorch-CPU oneDNN convs + numpy warp/resize restatement); scaled by the conv-FLOP ratio '
-                  f'{ratio:.5f} to a 1080p 2x2-tiled frame; the TF2 reference itself is not installable here',
-        'seconds': round(total, 3),
+        'value': round(1.0 / (4 * dt), 6), 'unit': 'frames/s (1080p 2x2-tiled: four tiles per frame, one after the other)',
+        'cores': ncores, 'kind': 'port',
+        'sample': f'{reps} x one 960x576 tile pair (one of the four tiles of a 1080p 2x2-tiled frame), published film_net, '
+                  f'{dt:.2f} s per tile ({total:.1f} s in all) on {ncores} threads (PyTorch-CPU oneDNN convs + numpy '
+                  f'warp/resize restatement, oracle/film_oracle.py); frame time = 4 tile times, nothing scaled; '
+                  f'the TF2 reference itself is not installable here',
+        'seconds_per_tile': round(dt, 3), 'seconds': round(total, 3),
     }
+
+
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        return so.getsockname()[1]
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: one rank per GPU via
+    torch.distributed.run on 127.0.0.1.  Refuses (exit code 2) when fewer than N GPUs are visible."""
+    import subprocess
+    if not args.plan_only:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible on this '
+                             f'node; refusing to print a {have}-GPU number as an {args.gpus}-GPU one.\n')
+            raise SystemExit(2)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def plan_only_run(args, world, rank):
+    """CPU rehearsal of the N-rank path (tests/test_dist_cpu.py): gloo rendezvous, rank 0 packs the weights,
+    broadcast of the weight set, every rank builds the plan of its shard of `--pairs` frame pairs, barrier +
+    max-over-ranks timing, rank 0 prints the line.  No compute: `value` is null and `plan_only` true."""
+    import torch.distributed as dist
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED, TINY
+    from film_hip.sharding import broadcast_weights, shard_range
+    opt = TINY if args.tiny_net else PUBLISHED
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+    eng = FilmEngine(opt, device=-1)
+    if rank == 0:
+        eng.set_weights(W.make_synthetic_weights(opt, seed=0))
+    if world > 1:
+        broadcast_weights(eng, dist, src=0)
+    H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
+    b, e = shard_range(args.pairs, world, rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    nops = 0
+    for _ in range(args.steps):
+        if e > b:
+            nops = len(eng.plan(ntiles if block else (e - b), tile_hw[0], tile_hw[1])['ops'])
+    dt = time.perf_counter() - t0
+    reported, units = 1, e - b
+    digest = float(np.abs(eng.export_packed()[::1013]).sum())
+    same = True
+    if world > 1:
+        dist.barrier()
+        t = torch.tensor([dt, float(units), 1.0], dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dt, units, reported = float(tmax[0]), int(t[1]), int(t[2])
+        d = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(d, torch.tensor([digest], dtype=torch.float64))
+        same = all(float(x) == float(d[0]) for x in d)
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({'metric': 'interpolated frames/sec @1080p', 'value': None, 'unit': 'frames/s', 'plan_only': True,
+                          'n_gpus': reported, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': round(dt / max(1, args.steps) * 1e3, 3), 'higher_is_better': True,
+                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': args.workload, 'pairs_sharded': units, 'plan_ops': nops,
+                                     'weights_identical_on_all_ranks': same}}), flush=True)
 
 
 def main():
@@ -118,13 +206,29 @@ def main():
                     help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
     ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
     ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
+    ap.add_argument('--plan-only', action='store_true',
+                    help='CPU rehearsal of the N-rank path: gloo + plan-only engine handles, no compute (tests)')
+    ap.add_argument('--tiny-net', action='store_true', help='with --plan-only: the small test architecture')
+    ap.add_argument('--pairs', type=int, default=8, help='with --plan-only: frame pairs sharded over the ranks')
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        relaunch_under_torchrun(args)          # does not return
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks\n')
+        raise SystemExit(2)
+    if args.plan_only:
+        return plan_only_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the engine has no CPU fallback')
+    if torch.cuda.device_count() <= local_rank:
+        sys.stderr.write(f'bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible\n')
+        raise SystemExit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     dist = None
@@ -180,10 +284,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    reported = 1
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        ones = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        reported = int(ones.item())
     assert out is not None and bool(torch.isfinite(out).all())
 
     result = None
@@ -234,23 +342,25 @@ def main():
         roofline = {
             'bound': 'mfma',
             'kernel': ('conv class = conv_wino43_kernel / conv_wino_kernel / conv_halo_kernel / conv_buf_kernel (fp32 v_mfma_f32_32x32x2_f32); '
-                       'FLOPs are the direct convolution\'s (SURVEY 8d) also where the Winograd F(4,3) / F(2,3) kernels execute 2x / 1.5x fewer')
+                       '`achieved` / `frac` count the FLOPs the matrix pipe executes (Winograd F(4,3) layers x1/2, F(2,3) x2/3, folded 2x2 layers x9/16 '
+                       'of the direct convolution)')
                       if not args.precision else
                       ('conv class in the opt-in split mode = conv_winox3_kernel / conv_halo_split_kernel '
                        '(v_mfma_f32_32x32x16_bf16, fp32 accumulate) + the fp32 kernels on the small / 2x2 layers; '
-                       'FLOPs are the direct fp32 convolution\'s, peak = dense bf16 MFMA peak / bf16 products per fp32 product'),
-            'achieved': round(conv_tflops, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-            'frac': round(conv_tflops / peak, 4), 'traffic': traffic if not args.precision else None,
+                       'peak = dense bf16 MFMA peak / bf16 products per fp32 product'),
+            'achieved': round(exec_tflops, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+            'frac': round(exec_tflops / peak, 4), 'traffic': traffic if not args.precision else None,
             'traffic_note': 'bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 PMC passes' if traffic else None,
             'launches_per_step': conv['launches'],
             'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
             'class_ms_per_step': round(conv['ms'], 3),
+            'executed_flops_per_step': exec_flops,
             'algorithmic_flops_per_step': conv['flops'],
             'all_conv_flops_per_step': alg_flops,
             'share_of_kernel_time': round(conv['ms'] / total_ms, 4),
-            'executed': {'achieved': round(exec_tflops, 3), 'frac': round(exec_tflops / peak, 4),
-                         'note': 'FLOPs the matrix pipe executes (Winograd F(4,3) layers x1/2, F(2,3) x2/3, folded 2x2 layers x9/16); `achieved` / '
-                                 '`frac` above count the direct convolution (SURVEY 8d) and can exceed the fp32 MFMA peak'},
+            'direct_equivalent': {'achieved': round(conv_tflops, 3), 'ratio_to_peak': round(conv_tflops / peak, 4),
+                                  'note': 'same launches priced with the direct convolution\'s FLOPs (SURVEY 8d formula); exceeds the fp32 MFMA '
+                                          'peak because Winograd / the sub-pixel fold execute fewer multiplies - an algorithmic saving, not a utilisation'},
         }
         extra = {}
         if 'warp' in cls:
@@ -262,10 +372,10 @@ def main():
                 'algorithmic_bytes_per_step': cls['warp']['bytes'],
             }
         extra['kernel_ms_per_step'] = {k: round(v['ms'], 3) for k, v in cls.items()}
-        value = world * args.steps * pairs / dt
+        value = reported * args.steps * pairs / dt
         result = {
             'metric': 'interpolated frames/sec @1080p', 'value': round(value, 4), 'unit': 'frames/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': reported, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32' if not args.precision else ('f32 via bf16x6 exact-split MFMA (opt-in mode)' if args.precision == 1 else 'bf16x3 split MFMA, f32 accumulate (opt-in mode)'),
             'data': 'synthetic',

@@ -127,6 +127,14 @@ class Interpolator:
   def engine(self) -> FilmEngine:
     return self._engine
 
+  @property
+  def align(self) -> Optional[int]:
+    return self._align
+
+  @property
+  def block_shape(self) -> Optional[List[int]]:
+    return self._block_shape
+
   def interpolate(self, x0: np.ndarray, x1: np.ndarray,
                   dt: np.ndarray) -> np.ndarray:
     """Mid-frame for every pair of the batch (reference: Interpolator.interpolate, :152-176).
@@ -152,9 +160,15 @@ class Interpolator:
           'block_height=%d should evenly divide height=%d.' % (block_height, height))
       assert width == (width // block_width) * block_width, (
           'block_width=%d should evenly divide width=%d.' % (block_width, width))
+      # The reference's tiled path takes ONE frame pair: image_to_patches reshapes the space_to_batch
+      # result to [num_blocks, ...] (eval/interpolator.py:94-98), which fails for B > 1.  Same here -
+      # no silent truncation; film_hip.torch_io.DeviceInterpolator.batch tiles whole batches.
+      x0 = np.reshape(x0, (-1, height, width, x0.shape[-1]))
+      x1 = np.reshape(x1, (-1, height, width, x1.shape[-1]))
+      if x0.shape[0] != 1:
+        raise ValueError('the tiled path (block_shape) takes one frame pair per call, got a batch of %d '
+                         '(reference: image_to_patches reshape, eval/interpolator.py:96-98)' % x0.shape[0])
       # The reference runs the patches one by one with B=1; they are independent, so all of
       # them go through the engine as one batch (identical per-patch arithmetic).
-      x0 = np.reshape(x0, (-1, height, width, x0.shape[-1]))[:1]
-      x1 = np.reshape(x1, (-1, height, width, x1.shape[-1]))[:1]
       return self._engine.interpolate_frames(x0, x1, align=self._align, block_shape=self._block_shape)
     return self.interpolate(x0, x1, dt)

@@ -4,6 +4,14 @@ DirectRunner, sorted with a natural-order key instead of natsort, mp4 via the ff
 
   cd frame-interpolation_amd
   python -m eval.interpolator_cli --model_path <model dir> --pattern "<root>/*" --times_to_interpolate 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+         -m eval.interpolator_cli --model_path <model dir> --pattern "<root>/*" --times_to_interpolate 3
+
+Multi-GPU (the reference maps directories over beam workers, eval/interpolator_cli.py:180-187): under torchrun
+every rank owns one GPU (LOCAL_RANK) and a contiguous share of the work - whole directories when there are at
+least as many as ranks, otherwise consecutive input pairs of each directory (a pair's recursion tree is
+independent of every other pair; output frame indices are global, so ranks write disjoint files).  No
+collective on the data path; weights are read from --model_path on rank 0 and broadcast once (RCCL).
 
 For every directory matching --pattern: frames *.png, *.jpg, *.jpeg (each group naturally sorted, groups
 concatenated in that order, as upstream) are expanded 2^T-fold and written to
@@ -92,15 +100,88 @@ def process_directory(directory: str, it, args) -> int:
     return len(frames)
 
 
+def plan_work(directories: List[str], world: int, rank: int):
+    """Work of `rank`: (whole_directories, [(directory, first_pair, end_pair, n_pairs)]).  With at least `world`
+    directories each rank takes whole directories (shard_range over the directory list, as the reference's ParDo
+    over directories); with fewer, the consecutive input pairs of every directory are dealt out instead."""
+    from film_hip.sharding import shard_range
+    pairs = [(d, max(0, len(list_input_frames(d)) - 1)) for d in directories]
+    pairs = [(d, n) for d, n in pairs if n > 0]
+    if world == 1 or len(pairs) >= world:
+        b, e = shard_range(len(pairs), world, rank)
+        return True, [(d, 0, n, n) for d, n in pairs[b:e]]
+    out = []
+    for d, n in pairs:
+        b, e = shard_range(n, world, rank)
+        if e > b:
+            out.append((d, b, e, n))
+    return False, out
+
+
+def process_pair_range(directory: str, first: int, end: int, n_pairs: int, it, args, clear: bool) -> int:
+    """Input pairs [first, end) of a directory: frame (pair p, step k) -> frame_%03d with index p * 2^T + k; the
+    rank that owns the last pair also writes the final input frame (eval/util.py:122-123)."""
+    inputs = list_input_frames(directory)
+    frames_dir = f'{directory}/interpolated_frames'
+    if clear:
+        output_frames([], frames_dir)
+    else:
+        os.makedirs(frames_dir, exist_ok=True)
+    step = 2 ** args.times_to_interpolate
+    n = 0
+    for p in range(first, end):
+        seq = list(util.interpolate_recursively_from_files(inputs[p:p + 2], args.times_to_interpolate, it))
+        keep = seq if p == n_pairs - 1 else seq[:-1]
+        for k, frame in enumerate(keep):
+            util.write_image(f'{frames_dir}/frame_{p * step + k:03d}.png', frame)
+        n += len(keep)
+    return n
+
+
 def main(argv=None) -> None:
     args = build_parser().parse_args(argv)
     if args.output_video:
         util.get_ffmpeg_path()
-    it = interpolator_lib.Interpolator(args.model_path, args.align, [args.block_height, args.block_width], precision=args.precision)
-    for directory in sorted(glob.glob(args.pattern)):
-        if os.path.isdir(directory):
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    block = [args.block_height, args.block_width]
+    directories = [d for d in sorted(glob.glob(args.pattern)) if os.path.isdir(d)]
+    if world == 1:
+        it = interpolator_lib.Interpolator(args.model_path, args.align, block, precision=args.precision)
+        for directory in directories:
             n = process_directory(directory, it, args)
             print(f'{directory}: {n} frames')
+        return
+    import torch
+    import torch.distributed as dist
+    from film_hip.sharding import sharded_interpolator
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f'rank {rank} needs GPU {local_rank}, only {torch.cuda.device_count()} visible')
+    torch.cuda.set_device(local_rank)
+    dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    it = sharded_interpolator(args.model_path, args.align, block, dist, local_rank, precision=args.precision)
+    whole, work = plan_work(directories, world, rank)
+    # stale frames are removed by rank 0 before anybody writes (a directory's pairs may be spread over ranks)
+    if rank == 0 and not whole:
+        for d in directories:
+            output_frames([], f'{d}/interpolated_frames')
+    dist.barrier()
+    for directory, b, e, n_pairs in work:
+        if whole:
+            n = process_directory(directory, it, args)
+        else:
+            n = process_pair_range(directory, b, e, n_pairs, it, args, clear=False)
+        print(f'[rank {rank}] {directory}: pairs [{b},{e}) of {n_pairs}, {n} frames')
+    dist.barrier()
+    if rank == 0 and args.output_video and not whole:
+        for d in directories:
+            files = sorted(glob.glob(f'{d}/interpolated_frames/frame_*.png'), key=natural_key)
+            if files:
+                write_video(f'{d}/interpolated.mp4', [util.read_image(f) for f in files], args.fps)
+    dist.destroy_process_group()
 
 
 if __name__ == '__main__':

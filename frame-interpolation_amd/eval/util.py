@@ -73,6 +73,38 @@ def _recursive_generator(
     yield from _recursive_generator(mid_frame, frame2, num_recursions - 1, interpolator, bar)
 
 
+def _device_driver(interpolator):
+    """The device-resident breadth-first driver (film_hip/recursive.py) for the HIP-backed Interpolator: the two
+    input frames go to HBM once, depth d of the recursion is ONE batched film_interpolate call on 2^(d-1) frame
+    pairs, and the 2^T - 1 generated frames come back once - instead of the reference's 2^T - 1 numpy round
+    trips with batch size 1 (eval/util.py:62-91).  Same frames, same order, same bits (tests/test_gpu_parity.py).
+    Any other callable (e.g. the CPU oracle in tests), or FILM_HOST_RECURSION=1, gets the reference-order host
+    generator above."""
+    engine = getattr(interpolator, 'engine', None)
+    if engine is None or os.environ.get('FILM_HOST_RECURSION') == '1':
+        return None
+    import torch
+    from film_hip import recursive
+    from film_hip.torch_io import DeviceInterpolator
+    dev = torch.device('cuda', engine.device)
+    dev_it = DeviceInterpolator(engine, align=interpolator.align, block_shape=interpolator.block_shape)
+
+    def run(frame1: np.ndarray, frame2: np.ndarray, num_recursions: int, bar=None):
+        if num_recursions == 0:
+            yield frame1
+            return
+        with torch.cuda.device(dev):
+            a = torch.from_numpy(np.ascontiguousarray(frame1, dtype=np.float32)).to(dev)
+            b = torch.from_numpy(np.ascontiguousarray(frame2, dtype=np.float32)).to(dev)
+            seq = recursive.interpolate_pair_recursively(a, b, num_recursions, dev_it)[:-1].cpu().numpy()
+        if bar is not None:
+            bar.update(seq.shape[0] - 1)
+        yield frame1
+        for k in range(1, seq.shape[0]):
+            yield seq[k]
+    return run
+
+
 def _progress(total: int):
     if tqdm is None:
         return None
@@ -86,9 +118,13 @@ def interpolate_recursively_from_files(
     (reference eval/util.py:94-123)."""
     n = len(frames)
     bar = _progress((n - 1) * (2 ** times_to_interpolate - 1))
+    driver = _device_driver(interpolator)
     for i in range(1, n):
-        yield from _recursive_generator(
-            read_image(frames[i - 1]), read_image(frames[i]), times_to_interpolate, interpolator, bar)
+        f1, f2 = read_image(frames[i - 1]), read_image(frames[i])
+        if driver is not None:
+            yield from driver(f1, f2, times_to_interpolate, bar)
+        else:
+            yield from _recursive_generator(f1, f2, times_to_interpolate, interpolator, bar)
     yield read_image(frames[-1])
 
 
@@ -99,8 +135,12 @@ def interpolate_recursively_from_memory(
     (reference eval/util.py:125-153)."""
     n = len(frames)
     bar = _progress((n - 1) * (2 ** times_to_interpolate - 1))
+    driver = _device_driver(interpolator)
     for i in range(1, n):
-        yield from _recursive_generator(frames[i - 1], frames[i], times_to_interpolate, interpolator, bar)
+        if driver is not None:
+            yield from driver(frames[i - 1], frames[i], times_to_interpolate, bar)
+        else:
+            yield from _recursive_generator(frames[i - 1], frames[i], times_to_interpolate, interpolator, bar)
     yield frames[-1]
 
 

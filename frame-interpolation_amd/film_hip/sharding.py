@@ -47,3 +47,28 @@ def broadcast_weights(engine, dist, src: int = 0, device=None) -> None:
         dist.broadcast(blob, src=src)
         if rank != src:
             engine.import_packed(blob.numpy())
+
+
+def sharded_interpolator(model_path, align, block_shape, dist, local_rank: int, precision: int = 0, options=None):
+    """eval.interpolator.Interpolator of this rank's GPU: rank 0 reads + packs the weights of `model_path`, every
+    other rank receives the packed blob by broadcast (RCCL over xGMI) instead of reading and repacking."""
+    import torch
+    from eval.interpolator import Interpolator
+    from .engine import FilmEngine
+    from .options import PUBLISHED
+    from . import weights as W
+    opt = options or PUBLISHED
+    rank = dist.get_rank()
+    if rank == 0:
+        it = Interpolator(model_path, align, block_shape, device=local_rank, options=opt, precision=precision)
+        engine = it.engine
+    else:
+        engine = FilmEngine(opt, device=local_rank)
+    broadcast_weights(engine, dist, src=0, device=torch.device('cuda', local_rank))
+    if rank != 0:
+        it = Interpolator.__new__(Interpolator)
+        it._options, it._engine = opt, engine
+        if precision:
+            engine.set_option('precision', int(precision))
+        it._align, it._block_shape = align or None, block_shape or None
+    return it

@@ -397,9 +397,10 @@ def _natural(s: str):
 def load_film_weights(prefix: str, opt=None, verify: bool = True, report: Optional[dict] = None) -> Dict[str, np.ndarray]:
     """Reads every film_net tensor of a bundle into {canonical name: float32 array}.
 
-    Rule 1: attribute-path patterns (see module docstring).  Rule 2, for whatever rule 1 did not place: a tensor of
-    the required shape among the unused float variables, taken in natural key order (inside film_net only the
-    consecutive [3,3,nf,nf] pairs repeat a shape, and those are index-ordered).  `report[name]` = (rule, key)."""
+    Rule 1: attribute-path patterns (see module docstring; the paths are the ones the reference's own layer code
+    produces - tests/test_ref_golden_cpu.py derives them by running it).  Rule 2, for whatever rule 1 did not place:
+    the unused float variable of the required shape, ONLY if that shape is unique on both sides; anything ambiguous
+    raises instead of guessing.  `report[name]` = (rule, key)."""
     from . import weights as W
     from .options import PUBLISHED
     opt = opt or PUBLISHED
@@ -424,14 +425,24 @@ def load_film_weights(prefix: str, opt=None, verify: bool = True, report: Option
             used.add(k)
     missing = [n for n in specs if n not in out]
     if missing:
+        # Rule 2 places a tensor ONLY when the match is unambiguous: exactly one unused variable has the shape and
+        # exactly one unplaced tensor wants it.  (Shapes repeat inside film_net - (3,3,256,256) is cfeat_conv_5,
+        # flow_predictor_shared/conv_1,2 and fusion/convs_2_2 - so "first fit" could silently permute weights.)
         pool = sorted((k for k in var_keys if k not in used), key=_natural)
+        ambiguous = []
         for name in missing:
-            for k in pool:
-                if k not in used and rd.entries[k].shape == specs[name]:
-                    out[name] = rd.tensor(k)
-                    rep[name] = ('shape', k)
-                    used.add(k)
-                    break
+            cands = [k for k in pool if k not in used and rd.entries[k].shape == specs[name]]
+            rivals = [n for n in missing if n not in out and specs[n] == specs[name]]
+            if len(cands) == 1 and len(rivals) == 1:
+                out[name] = rd.tensor(cands[0])
+                rep[name] = ('shape', cands[0])
+                used.add(cands[0])
+            elif cands:
+                ambiguous.append((name, cands[:4]))
+        if ambiguous:
+            lines = '; '.join(f'{n} <- one of {c}' for n, c in ambiguous[:6])
+            raise ValueError(f'{prefix}: {len(ambiguous)} tensor(s) could not be placed by their object-graph path and '
+                             f'their shape is not unique among the remaining variables - refusing to guess: {lines}')
     still = [n for n in specs if n not in out]
     if still:
         raise KeyError(f'{prefix}: no variable found for {still[:4]}{"..." if len(still) > 4 else ""} '

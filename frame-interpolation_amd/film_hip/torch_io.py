@@ -78,5 +78,8 @@ class DeviceInterpolator:
 
     def __call__(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
         if self._block_shape is not None and self._block_shape[0] * self._block_shape[1] > 1:
-            return self._run(x0[:1], x1[:1], self._block_shape)
+            if x0.shape[0] != 1:    # the reference's tiled path takes one pair (eval/interpolator.py:96-98); see .batch
+                raise ValueError(f'the tiled path takes one frame pair per call, got a batch of {x0.shape[0]}; '
+                                 'use DeviceInterpolator.batch for batches of tiled frames')
+            return self._run(x0, x1, self._block_shape)
         return self._run(x0, x1, None)

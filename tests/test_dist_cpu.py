@@ -75,3 +75,45 @@ def test_weight_broadcast_world2_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_bench_launcher_world2_plan_only():
+    """`python bench.py --gpus 2` end to end on CPU: bench.py re-executes itself under torch.distributed.run with two
+    ranks (127.0.0.1), gloo rendezvous, rank 0 packs + broadcasts the weights, both ranks shard the job, build their
+    plan, barrier, max-over-ranks timing, ONE JSON line from rank 0 with n_gpus = the ranks that reported."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--plan-only', '--tiny-net',
+                          '--steps', '2', '--warmup', '0', '--pairs', '5'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    r = json.loads(lines[0])
+    assert r['n_gpus'] == 2 and r['plan_only'] is True and r['value'] is None
+    assert r['config']['pairs_sharded'] == 5 and r['config']['weights_identical_on_all_ranks'] is True
+    assert r['config']['plan_ops'] > 20
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 2` on a box with fewer GPUs exits non-zero with a clear message instead of printing
+    a 1-GPU number (this container has none)."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('needs a box with fewer than 2 GPUs')
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 2
+    assert 'refusing' in out.stderr and not [l for l in out.stdout.splitlines() if l.startswith('{')]
+    # a torchrun world that disagrees with --gpus is refused as well
+    env['WORLD_SIZE'] = '4'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--plan-only'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 2 and 'WORLD_SIZE=4' in out.stderr

@@ -1,0 +1,177 @@
+"""The oracle (oracle/film_oracle.py) against vectors produced by the reference's own Python.
+
+tests/golden/ref_*.npz come from tools/make_ref_golden.py: /root/reference/models/film_net/*.py,
+eval/interpolator.py and eval/util.py imported unmodified and executed over oracle/tf_shim (PyTorch built-ins in
+place of the TF ops).  They pin the oracle's GRAPH restatement (wiring, channel orders, weight naming, pad / patch /
+recursion logic) to the reference's code, and its hand-written op arithmetic to independently written built-ins -
+through the whole 7-level recursive network, in float32 and float64.  When tests/golden/tf_*.npz (real TensorFlow,
+`--backend tf`) exist they are used instead and the op semantics are pinned too; until then:
+PARITY WITH TENSORFLOW ITSELF IS UNPINNED (see test_tensorflow_pinning_status)."""
+import numpy as np
+import pytest
+
+import golden_util as G
+import inputs as TI
+from conftest import oracle_options
+
+F32_IMAGE_TOL = 2e-5      # two fp32 evaluations of a 34 M-parameter net with different summation orders
+F64_TOL = 1e-11           # float64 oracle vs float64 reference graph: same semantics => round-off only
+
+
+@pytest.fixture(scope='module')
+def published_weights():
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    return W.make_synthetic_weights(PUBLISHED, seed=0)
+
+
+def _check_aux(g, aux, report):
+    report['x0_warped'] = G.diff(g, 'x0_warped', aux['x0_warped'])
+    report['x1_warped'] = G.diff(g, 'x1_warped', aux['x1_warped'])
+    for d in ('forward', 'backward'):
+        for l, v in enumerate(aux[f'{d}_residual_flow_pyramid']):
+            report[f'{d}_residual_flow{l}'] = G.diff(g, f'{d}_residual_flow{l}', v)
+        for l, v in enumerate(aux[f'{d}_flow_pyramid']):
+            report[f'{d}_flow{l}'] = G.diff(g, f'{d}_flow{l}', v)
+
+
+def test_tiny_net_all_taps_f32_and_f64(tiny_weights):
+    from film_hip.options import TINY
+    from oracle import film_oracle as fo
+    g, prov = G.load('tiny')
+    x0, x1 = TI.frame_pair(2, 32, 40, seed=11, shift=(3, -4), fg_shift=(-2, 5))
+    G.check_inputs(g, x0, x1)
+    img, aux = fo.film_forward(x0, x1, tiny_weights, oracle_options(TINY), return_aux=True)
+    report = {'image': G.diff(g, 'image', img)}
+    _check_aux(g, aux, report)
+    print(prov, {k: float(f'{v:.1e}') for k, v in report.items()})
+    assert max(report.values()) < F32_IMAGE_TOL, report
+    if 'image_f64' in g.files:
+        w64 = {k: v.astype(np.float64) for k, v in tiny_weights.items()}
+        img64 = fo.film_forward(x0.astype(np.float64), x1.astype(np.float64), w64, oracle_options(TINY))
+        d64 = float(np.abs(img64 - g['image_f64']).max())
+        print('float64 oracle vs float64 reference graph:', d64)
+        assert d64 < F64_TOL
+
+
+def test_published_256_taps_f32_and_f64(published_weights):
+    """BASELINE configs[1].  Options come from the reference's film_net-L1.gin (stored in the golden)."""
+    from film_hip.options import PUBLISHED as P
+    from oracle import film_oracle as fo
+    g, prov = G.load('256')
+    assert list(g['gin_options']) == [P.pyramid_levels, P.fusion_pyramid_levels, P.specialized_levels, P.sub_levels,
+                                      P.filters] + list(P.flow_convs) + list(P.flow_filters)
+    x0, x1 = TI.frame_pair(1, 256, 256, seed=1)
+    G.check_inputs(g, x0, x1)
+    img, aux = fo.film_forward(x0, x1, published_weights, fo.Options(), return_aux=True)
+    report = {'image': float(np.abs(img - g['image_full']).max())}
+    _check_aux(g, aux, report)
+    print(prov, {k: float(f'{v:.1e}') for k, v in report.items()})
+    assert max(report.values()) < F32_IMAGE_TOL, report
+    assert float(np.abs(g['forward_flow0.s4']).max()) > 3.0, 'the case is meant to carry flows of several pixels'
+    if 'image_f64' in g.files:
+        w64 = {k: v.astype(np.float64) for k, v in published_weights.items()}
+        img64, aux64 = fo.film_forward(x0.astype(np.float64), x1.astype(np.float64), w64, fo.Options(), return_aux=True)
+        d64 = float(np.abs(img64 - g['image_f64']).max())
+        f64 = max(float(np.abs(aux64[f'{d}_flow_pyramid'][0][:, ::4, ::4] - g[f'{d}_flow0_f64.s4']).max())
+                  for d in ('forward', 'backward'))
+        print('float64 oracle vs float64 reference graph: image', d64, 'flow0', f64,
+              '| f32 oracle vs f64 truth', float(np.abs(img - g['image_f64']).max()))
+        assert d64 < F64_TOL and f64 < F64_TOL
+
+
+def test_weight_names_and_object_graph_paths_come_from_the_reference_code():
+    """The 41 Conv2D layers the reference code creates, with the canonical name the golden script gave each (name
+    chain for named layers, attribute path for the decoder's unnamed ones) and the object-graph path Keras tracks
+    them under - against film_hip.weights.weight_specs and BOTH directions of the TF-free SavedModel reader's key
+    mapping (so its attribute-path patterns are the reference's real attribute names, not a guess)."""
+    from film_hip import weights as W
+    from film_hip import tf_bundle as tb
+    from film_hip.options import PUBLISHED
+    g, _ = G.load('256')
+    rows = [str(r).split('|') for r in g['conv_names']]
+    names = [r[0] for r in rows]
+    spec_names = [n for n, _, _ in W.weight_specs(PUBLISHED)]
+    assert sorted(names) == sorted(spec_names) and len(set(names)) == 41
+    assert list(g['model_layers']) == ['feat_net', 'predict_flow', 'fusion']     # layer_with_weights-0,1,2
+    lw = {'feat_net': 0, 'predict_flow': 1, 'fusion': 2}
+    for name, chain, path in rows:
+        for var in ('kernel', 'bias'):
+            key = f'layer_with_weights-{lw[chain.split("/")[0]]}/{path}/{var}'
+            assert tb.canonical_name(key, PUBLISHED.specialized_levels) == f'{name}/{var}', key
+            assert tb.checkpoint_key(f'{name}/{var}', PUBLISHED) == key + tb.VAR_SUFFIX, key
+
+
+def test_photos_1024x768_interpolator_test_path(published_weights):
+    """BASELINE configs[0]: photos/one.png + two.png through Interpolator(align=64, block_shape=[1,1]) and
+    write_image's uint8 rounding (eval/interpolator_test.py:73-99, eval/util.py:44-59)."""
+    from oracle import film_oracle as fo
+    g, prov = G.load('photos')
+    a = TI.read_png(G.GOLDEN + '/photo_one.png')
+    b = TI.read_png(G.GOLDEN + '/photo_two.png')
+    G.check_inputs(g, a, b)
+    it = fo.OracleInterpolator(published_weights, align=64, block_shape=[1, 1])
+    mid = it(a[None], b[None], np.full((1,), 0.5, np.float32))
+    d = G.diff(g, 'image', mid)
+    u8 = (np.clip(mid[0] * 255.0, 0.0, 255.0) + 0.5).astype(np.uint8)[::4, ::4]
+    du8 = int(np.abs(u8.astype(np.int32) - g['image_u8.s4'].astype(np.int32)).max())
+    print(prov, 'photos image max|d|', d, 'uint8 max|d|', du8)
+    assert d < F32_IMAGE_TOL and du8 <= 1
+
+
+def test_vimeo_batch_of_8(published_weights):
+    """BASELINE configs[3]: a batch of eight 448x256 pairs in one model call (B > 1 through the reference graph)."""
+    from oracle import film_oracle as fo
+    g, prov = G.load('vimeo')
+    x0, x1 = TI.frame_pair(8, 256, 448, seed=3)
+    G.check_inputs(g, x0, x1)
+    mid = fo.OracleInterpolator(published_weights, align=64)(x0, x1, np.full((8,), 0.5, np.float32))
+    d = G.diff(g, 'image', mid)
+    print(prov, 'vimeo batch max|d|', d)
+    assert d < F32_IMAGE_TOL
+
+
+def test_1080p_tile_of_the_2x2_tiled_frame(published_weights):
+    """BASELINE configs[2] (the config the metric is quoted on): the reference's tiled Interpolator on a 1920x1080
+    pair.  The CPU suite recomputes the top-left 960x540 patch (one 960x576 tile, ~2.3 TFLOP); the GPU suite
+    compares the whole frame."""
+    from oracle import film_oracle as fo
+    g, prov = G.load('1080p')
+    x0, x1 = TI.frame_pair(1, 1080, 1920, seed=2, shift=(11, -17), fg_shift=(-9, 21))
+    G.check_inputs(g, x0, x1)
+    it = fo.OracleInterpolator(published_weights, align=64)
+    tile = it.interpolate(x0[:, :540, :960], x1[:, :540, :960], None)
+    want = g['image.s4'][:, :135, :240]
+    d = float(np.abs(tile[:, ::4, ::4] - want).max())
+    print(prov, '1080p tile (0,0) max|d|', d)
+    assert d < F32_IMAGE_TOL
+
+
+def test_recursive_driver_order_and_png_rounding(published_weights):
+    """frames of eval/util.py:interpolate_recursively_from_memory (T=2, 2x1 tiles) in the reference's
+    depth-first order, and write_image's rounding - against the repo's host driver twin over the oracle."""
+    from eval import util as host_util
+    from oracle import film_oracle as fo
+    g, prov = G.load('recursive')
+    x0, x1 = TI.frame_pair(1, 200, 176, seed=4, shift=(6, -8), fg_shift=(-4, 9))
+    G.check_inputs(g, x0, x1)
+    it = fo.OracleInterpolator(published_weights, align=64, block_shape=[2, 1])
+    frames = list(host_util.interpolate_recursively_from_memory([x0[0], x1[0]], 2, it))
+    assert len(frames) == 5
+    got = np.stack(frames)
+    d = float(np.abs(got - g['frames']).max())
+    u8 = np.stack([host_util.to_uint8(f) for f in frames])
+    du8 = int(np.abs(u8.astype(np.int32) - g['frames_u8'].astype(np.int32)).max())
+    print(prov, 'recursive frames max|d|', d, 'uint8', du8)
+    assert d < 5e-5 and du8 <= 1          # second-generation frames feed first-generation round-off back in
+    assert np.array_equal(got[0], x0[0]) and np.array_equal(got[4], x1[0])
+
+
+def test_tensorflow_pinning_status():
+    """Not a pass/fail of the code: states in the test log whether any vector here was produced by TensorFlow."""
+    cases = ['tiny', '256', 'photos', 'vimeo', '1080p', 'recursive']
+    pinned = [c for c in cases if G.pinned_by_tensorflow(c)]
+    if not pinned:
+        pytest.skip('parity unpinned against TensorFlow itself: tests/golden/tf_*.npz absent (no TF in this image); '
+                    'the ref_*.npz vectors pin the graph to the reference\'s own code over PyTorch built-ins. '
+                    'Recipe: python tools/make_ref_golden.py --backend tf')

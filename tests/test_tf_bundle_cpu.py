@@ -95,22 +95,36 @@ def test_published_keys_and_shared_predictor_aliases():
         assert tb.canonical_name(key[:-len(tb.VAR_SUFFIX)], s) == name
 
 
-def test_shape_fallback_when_paths_are_unknown(tmp_path, tiny_weights):
-    """Keys that follow no known attribute path: tensors are placed by shape in natural key order."""
+def test_shape_fallback_places_only_unambiguous_tensors(tmp_path, tiny_weights):
+    """Keys that follow no known attribute path: a tensor is placed by shape only when exactly one unused variable
+    and exactly one unplaced tensor have that shape; repeated shapes (film_net has many) raise instead of guessing."""
     from film_hip import tf_bundle as tb
     from film_hip import weights as W
     from film_hip.options import TINY
     names = [n for spec, _, _ in W.weight_specs(TINY) for n in (spec + '/kernel', spec + '/bias')]
-    tensors = {f'model/variables/{i}{tb.VAR_SUFFIX}': tiny_weights[n] for i, n in enumerate(names)}
+    shapes = [tuple(tiny_weights[n].shape) for n in names]
+    unique = [n for n in names if shapes.count(tuple(tiny_weights[n].shape)) == 1]
+    assert unique and len(unique) < len(names)
+    # every tensor under its proper object-graph key except the unique-shaped ones, which get an unknown path
+    tensors = {}
+    for i, n in enumerate(names):
+        key = f'model/variables/{i}{tb.VAR_SUFFIX}' if n in unique else tb.checkpoint_key(n, TINY)
+        tensors[key] = tiny_weights[n]
     tensors['optimizer/iter' + tb.VAR_SUFFIX] = np.zeros((), np.float32)
     prefix = str(tmp_path / 'variables' / 'variables')
     tb.write_bundle(prefix, tensors, object_graph=False)
     report = {}
     got = tb.load_film_weights(prefix, TINY, report=report)
-    assert all(rule == 'shape' for rule, _ in report.values())
+    assert {n for n, (rule, _) in report.items() if rule == 'shape'} == set(unique)
     for n in names:
         assert np.array_equal(got[n], tiny_weights[n]), n
-    del tensors[f'model/variables/0{tb.VAR_SUFFIX}']
+    # all keys unknown: shapes repeat -> refuse, naming the candidates
+    tensors = {f'model/variables/{i}{tb.VAR_SUFFIX}': tiny_weights[n] for i, n in enumerate(names)}
+    tb.write_bundle(prefix, tensors, object_graph=False)
+    with pytest.raises(ValueError, match='refusing to guess'):
+        tb.load_film_weights(prefix, TINY)
+    # a missing tensor is still a KeyError
+    tensors = {tb.checkpoint_key(n, TINY): tiny_weights[n] for n in names[1:]}
     tb.write_bundle(prefix, tensors, object_graph=False)
     with pytest.raises(KeyError):
         tb.load_film_weights(prefix, TINY)
