@@ -202,6 +202,9 @@ def main():
     ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--lanes', type=int, default=1, choices=[0, 1],
+                    help='0: replay the graph on ONE stream (serialised kernels: what the committed rocprofv3 kernel trace uses, '
+                         'so that per-kernel durations are not inflated by overlap); 1 (default): two-stream graph')
     ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
                     help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
     ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
@@ -256,6 +259,8 @@ def main():
         eng.set_option('tune_ms', int(os.environ['FILM_TUNE_MS']))
     if args.no_graph:
         eng.set_option('graph', 0)
+    if not args.lanes:
+        eng.set_option('lanes', 0)
     if args.precision:
         eng.set_option('precision', args.precision)
         args.no_split = True
@@ -383,7 +388,7 @@ def main():
                                    f'{ntiles} tile(s) of {tile_hw[1]}x{tile_hw[0]} in one batch, film_net published '
                                    f'config, seeded synthetic weights, t=0.5',
                        'frames_per_step_per_gpu': pairs, 'parallelism': f'{world} independent GPU(s), weights RCCL-broadcast once',
-                       'graph': not args.no_graph},
+                       'graph': not args.no_graph, 'lanes': args.lanes},
             'roofline': roofline,
         }
         result.update(extra)

@@ -14,9 +14,12 @@
 //     v5 = 4 d1 - 5 d3 + d5            u5 = g2                              m_nu = sum_dy sum_c v_nu * u_nu
 // fp32 throughout; on a K = 4608 test sum the rounding error is 3.9e-6 relative (F(2,3): 8.6e-7, direct: 6.4e-7).
 //
-//   * a workgroup owns TH rows x 128 pixels (32 quads = one 32-row MFMA tile per row) x BN output channels;
+//   * a workgroup owns TH rows x 4*QW pixels x BN output channels; QW = quads per patch row: 32 (128 pixels, one 32-row
+//     MFMA tile per patch row) or 16 (64 pixels, one MFMA tile per TWO patch rows: lanes 0-15 row r, 16-31 row r+1).
+//     The QW = 16 tiles are 4-wave workgroups with 72 KB of LDS: TWO per CU, whose barriers / fragment waits / epilogues
+//     are not in phase, and twice as many (half-size) workgroups per layer for the tails of the 120-wide level;
 //   * K chunks of 8 channels; the (TH+2) halo rows of a chunk are transformed ONCE on the way into LDS, image
-//     [halo row][nu 6][quad 32][8 channels] (32-byte rows, K-halves swapped on bit 3 of the row: conflict-free b128);
+//     [halo row][nu 6][quad QW][8 channels] (32-byte rows, K-halves swapped on bit 3 of the quad: conflict-free b128);
 //   * the six nu planes are independent GEMMs: wave half h accumulates nu = 3h .. 3h+2 for its TM rows x TN channel tiles
 //     (TM*TN*3 accumulator tiles per wave) and the halves swap partial output sums through LDS in the epilogue;
 //   * weights [Cout][chunk][dy][nu][8] (192 contiguous bytes per dy stage and channel) through a 3-slot LDS ring
@@ -25,17 +28,24 @@
 #pragma once
 #include "conv_buf_impl.h"
 
-template <int TH, int BN, int TM, int TN, int FLAGS>
-__global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino43_kernel(ConvParams p) {
-  constexpr int RG = TH / TM, NG = BN / (32 * TN), PW = RG * NG, NW = 2 * PW, NT = NW * 64;
+enum { W43_F_SETPRIO = 64 };   // FLAGS bit (experiments): raise the wave priority around the MFMA groups
+
+template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32>
+__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) void conv_wino43_kernel(ConvParams p) {
+  constexpr int RPT = 32 / QW;                 // patch rows per 32-quad MFMA tile
+  constexpr int MT = TH / RPT;                 // MFMA row tiles per patch; TM of them per wave
+  constexpr int RG = MT / TM, NG = BN / (32 * TN), PW = RG * NG, NW = 2 * PW, NT = NW * 64;
   constexpr int HR = TH + 2;
-  constexpr int A_STAGE = HR * 6 * 32 * 8;     // floats: [hy][nu][quad][8]
+  constexpr int A_PLANE = QW * 8;              // floats of one nu plane of a halo row
+  constexpr int A_STAGE = HR * 6 * A_PLANE;    // floats: [hy][nu][quad][8]
   constexpr int B_PLANE = BN * 8;              // floats of one nu plane of a stage
   constexpr int B_STAGE = 6 * B_PLANE;
-  constexpr int ITEMS = HR * 32 * 2;           // (halo row, quad, 4-channel group)
+  constexpr int ITEMS = HR * QW * 2;           // (halo row, quad, 4-channel group)
   constexpr int BU = BN * 12;                  // float4 units of one weight stage
   constexpr int BLD = (BU + NT - 1) / NT;
-  static_assert(TH % TM == 0 && BN % (32 * TN) == 0 && ITEMS <= NT && 2 * ITEMS > NT, "bad tile");
+  constexpr int PXW = 4 * QW;                  // patch width in pixels
+  static_assert(QW == 32 || QW == 16, "quads per patch row");
+  static_assert(TH % RPT == 0 && MT % TM == 0 && BN % (32 * TN) == 0 && ITEMS <= NT && 2 * ITEMS > NT, "bad tile");
   static_assert(2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + 3 * B_STAGE, "exchange buffer does not fit");
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
@@ -61,23 +71,23 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
     bx = nl / nby;
     by = nl - bx * nby;
   }
-  const int ntx = (p.W + 127) >> 7, nty = (p.H + TH - 1) / TH;
+  const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
   const int img = bx / (ntx * nty);
   const int trem = bx - img * (ntx * nty);
-  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * 128;
+  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * PXW;
   const int n0 = by * BN;
 
   // ---- the A staging item of this thread: (halo row hy, quad tq, channel group q); threads past the last item repeat
   // one (same values to the same LDS address) so that the staging code has no divergent branch -------------------------
   int f = t;
   if (f >= ITEMS) f -= ITEMS;
-  const int aq = f & 1, tq = (f >> 1) & 31, ahy = f >> 6;
+  const int aq = f & 1, tq = (f >> 1) % QW, ahy = (f >> 1) / QW;
   const int a_y = y0 - 1 + ahy, a_x = x0 - 1 + 4 * tq;
   unsigned a_ok = 0;          // bit j: pixel a_x + j is inside the image (and the row is)
   if (a_y >= 0 && a_y < p.H)
     for (int j = 0; j < 6; ++j)
       if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
-  const int a_lds = ((ahy * 6) * 32 + tq) * 8 + ((aq ^ ((tq >> 3) & 1)) << 2);   // float index of nu = 0
+  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ ((tq >> 3) & 1)) << 2);   // float index of nu = 0
   const int scol = aq * 4;
   unsigned a_off = 0, a_pix = 0;
   conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
@@ -135,7 +145,7 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
       v[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
     }
 #pragma unroll
-    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<bf4*>(As + nu * 256) = v[nu];   // nu planes: 32 rows x 8 floats apart
+    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<bf4*>(As + nu * A_PLANE) = v[nu];   // nu planes: QW rows x 8 floats apart
   };
   auto next_chunk = [&](int kc_next) {
     if (kc_next >= nkc) { chunk_ok = false; return; }
@@ -167,9 +177,10 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
   // ---- fragment addresses in float4 units: row * 2 + (K-half ^ bit 3 of the row) -------------------------------------
   const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
   constexpr int A_STAGE4 = A_STAGE / 4, B_STAGE4 = B_STAGE / 4, B_PLANE4 = B_PLANE / 4;
-  const int wy = rg * TM;
-  const int swb = (l31 >> 3) & 1;
-  const int a_ad = ((wy * 6 + 3 * h) * 32 + l31) * 2 + (half ^ swb);     // + ((mt + dy) * 6 + j) * 64, stage
+  const int wm = rg * TM;                    // first MFMA row tile of this wave
+  const int lrow = l31 / QW, lq = l31 % QW;  // lane -> (patch row inside the tile, quad)
+  const int swb = (lq >> 3) & 1;
+  const int a_ad = (((wm * RPT + lrow) * 6 + 3 * h) * QW + lq) * 2 + (half ^ swb);     // + ((mt * RPT + dy) * 6 + j) * QW * 2, stage
   const int b_ad = 2 * A_STAGE4 + (3 * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
   int a_cur = a_ad;
 
@@ -177,12 +188,13 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
   auto fetch = [&](auto dy_c, auto j_c, int a_base) {
     constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) fa[J][mt] = smem4[a_base + ((mt + DY) * 6 + J) * 64];
+    for (int mt = 0; mt < TM; ++mt) fa[J][mt] = smem4[a_base + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt) fb[J][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
   };
   auto compute = [&](auto j_c) {
     constexpr int J = decltype(j_c)::value;
+    if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -190,6 +202,7 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
           acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J][mt][k], fb[J][nt][k], acc[mt][J][nt], 0, 0, 0);
+    if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
@@ -264,12 +277,13 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
         const float bv = p.bias[n];
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
-          const int y = y0 + wy + mt;
-          if (y >= p.H) continue;
-          const size_t rowbase = ((size_t)img * p.H + y) * p.W;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int x = x0 + 4 * ((r & 3) + 8 * (r >> 2) + 4 * half) + 2 * H + round;
+            const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row MFMA tile
+            const int y = y0 + (wm + mt) * RPT + mrow / QW;
+            if (y >= p.H) continue;
+            const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+            const int x = x0 + 4 * (mrow % QW) + 2 * H + round;
             const float got = take[((mt * TN + nt) * 16 + r) * 64];
             const float ma = acc[mt][1][nt][r], mb = acc[mt][2][nt][r], m0 = acc[mt][0][nt][r];
             float v;
@@ -287,12 +301,12 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_wino4
   else finish(std::integral_constant<int, 1>{});
 }
 
-template <int TH, int BN, int TM, int TN, int FLAGS>
+template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32>
 hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = (2 * (size_t)(TH + 2) * 6 * 32 * 8 + 3 * 6 * (size_t)BN * 8) * sizeof(float);
-  constexpr int NT = (TH / TM) * (BN / (32 * TN)) * 128;
+  constexpr size_t lds = (2 * (size_t)(TH + 2) * 6 * QW * 8 + 3 * 6 * (size_t)BN * 8) * sizeof(float);
+  constexpr int NT = ((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128;
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = conv_wino43_kernel<TH, BN, TM, TN, FLAGS>;
+  auto kern = conv_wino43_kernel<TH, BN, TM, TN, FLAGS, QW>;
   if constexpr (lds > 64 * 1024) {
     static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
     int dev = 0;
@@ -303,7 +317,7 @@ hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
       if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
-  const int ntx = (p.W + 127) / 128, nty = (p.H + TH - 1) / TH;
+  const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();

@@ -84,6 +84,7 @@ struct OpDesc {
   int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
+  View in3, out2;   // warp: coarser flow to upsample / the upsampled flow it stores; flow heads: in2 = upsampled flow, out2 = v = out + in2
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
   float fscale = 1.f;
   int64_t n = 0;
@@ -163,6 +164,7 @@ struct film_handle {
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
+  int opt_fuse = 1;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
@@ -626,15 +628,27 @@ struct Planner {
       if (l == L - 1) {
         sb.v = view(feat[l], 0, 0, fc[l]); sb.boff = B; sb.bmod = N2;  // the other image's features
       } else {
-        OpDesc up;
-        up.kind = OP_FLOW_UP; up.tag = tg + ":resize2x";
-        up.in = view(v[l + 1], 0, 0, 2); up.out = view(vup[l], 0, 0, 2);
-        up.NB = N2; up.H = HL(l + 1); up.W = WL(l + 1);
-        up.bytes = 4.0 * N2 * Hl * Wl * 2 * 1.25;
-        P->ops.push_back(up);
-        for (int d = 0; d < 2; ++d)  // warp the OTHER image's features with this direction's flow
+        if (!h->opt_fuse) {
+          OpDesc up;
+          up.kind = OP_FLOW_UP; up.tag = tg + ":resize2x";
+          up.in = view(v[l + 1], 0, 0, 2); up.out = view(vup[l], 0, 0, 2);
+          up.NB = N2; up.H = HL(l + 1); up.W = WL(l + 1);
+          up.bytes = 4.0 * N2 * Hl * Wl * 2 * 1.25;
+          P->ops.push_back(up);
+        }
+        for (int d = 0; d < 2; ++d) {  // warp the OTHER image's features with this direction's flow
           warp(tg + ":warp_d" + std::to_string(d), view(feat[l], (1 - d) * B, 0, fc[l]), view(vup[l], d * B, 0, 2),
                view(warped[l], d * B, 0, fc[l]), B, Hl, Wl, 1.f);
+          if (h->opt_fuse) {
+            // tf.image.resize(2 * v) (pyramid_flow_estimator.py:155) inside the warp: the flow of this level is computed
+            // from the coarser level's v by every thread of a pixel and stored once (to vup, which v = res + up reads)
+            OpDesc& w = P->ops.back();
+            w.tag += "+resize2x";
+            w.in2 = View();
+            w.in3 = view(v[l + 1], d * B, 0, 2);
+            w.out2 = view(vup[l], d * B, 0, 2);
+          }
+        }
         sb.v = view(warped[l], 0, 0, fc[l]);
       }
       View cur = scratch(fp[0], nf);
@@ -652,6 +666,11 @@ struct Planner {
         SegDesc s; s.v = cur;
         conv(tg, l3, {s}, hid, N2, Hl, Wl, true);
         conv_pw(tg, l4, hid, view(res[l], 0, 0, 2), (int64_t)N2 * Hl * Wl, false);
+        if (h->opt_fuse && l < L - 1) {   // v = res + up in the head's epilogue
+          OpDesc& pw = P->ops.back();
+          pw.tag += "+v=res+up";
+          pw.in2 = view(vup[l], 0, 0, 2); pw.out2 = view(v[l], 0, 0, 2);
+        }
       } else {  // nf / 2 == 16: both 1x1 convs in one kernel, the 16-channel hidden layer stays in registers
         const LayerPack& L3 = h->layers[h->layer_idx.at(l3)];
         const LayerPack& L4 = h->layers[h->layer_idx.at(l4)];
@@ -660,9 +679,13 @@ struct Planner {
         op.in = cur; op.out = view(res[l], 0, 0, 2); op.n = (int64_t)N2 * Hl * Wl; op.Ctot = nf;
         op.w_off = L3.w_off; op.b_off = L3.b_off; op.w2_off = L4.w_off; op.b2_off = L4.b_off;
         op.flops = 2.0 * op.n * (nf * 16 + 16 * 2); op.bytes = 4.0 * op.n * (nf + 2);
+        if (h->opt_fuse && l < L - 1) {
+          op.tag += "+v=res+up";
+          op.in2 = view(vup[l], 0, 0, 2); op.out2 = view(v[l], 0, 0, 2);
+        }
         P->ops.push_back(op);
       }
-      if (l < L - 1) {
+      if (l < L - 1 && !h->opt_fuse) {
         OpDesc ad;
         ad.kind = OP_FLOW_ADD; ad.tag = tg + ":v=res+up";
         ad.in = view(res[l], 0, 0, 2); ad.in2 = view(vup[l], 0, 0, 2); ad.out = view(v[l], 0, 0, 2);
@@ -733,7 +756,9 @@ struct Planner {
     rd.clear(); wr.clear();
     if (op.kind == OP_CONV) for (int i = 0; i < op.nseg; ++i) rd.push_back(access(op.seg[i].v));
     else { if (op.in.buf >= 0) rd.push_back(access(op.in)); if (op.in2.buf >= 0) rd.push_back(access(op.in2)); }
+    if (op.in3.buf >= 0) rd.push_back(access(op.in3));
     if (op.out.buf >= 0) wr.push_back(access(op.out));
+    if (op.out2.buf >= 0) wr.push_back(access(op.out2));
   }
   // For every op: the LAST op of the other lane it conflicts with (RAW, WAR or WAW on overlapping channels of a
   // buffer).  Waiting for the last one is enough: a lane executes in program order.
@@ -794,6 +819,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.in = cptr(arena, op.in); p.istride = op.in.stride; p.Cin = op.Ctot;
       p.w3 = wts + op.w_off; p.b3 = wts + op.b_off; p.w4 = wts + op.w2_off; p.b4 = wts + op.b2_off;
       p.out = mptr(arena, op.out); p.M = (int)op.n;
+      if (op.out2.buf >= 0) { p.add = cptr(arena, op.in2); p.sum = mptr(arena, op.out2); }
       return film_launch_flow_head(p, s);
     }
     case OP_CONV_PW: {
@@ -802,6 +828,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.w = wts + op.w_off; p.bias = wts + op.b_off;
       p.out = mptr(arena, op.out); p.ostride = op.out.stride; p.Cout = op.Cout; p.leaky = op.leaky;
       p.M = (int)op.n;
+      if (op.out2.buf >= 0) { p.add = cptr(arena, op.in2); p.sum = mptr(arena, op.out2); }
       return film_launch_conv_pw(p, s);
     }
     case OP_POOL: {
@@ -823,9 +850,10 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
     case OP_WARP: {
       WarpParams p{};
       p.src = cptr(arena, op.in); p.sstride = op.in.stride; p.C = op.in.C;
-      p.flow = cptr(arena, op.in2); p.fscale = op.fscale;
+      p.flow = op.in2.buf >= 0 ? cptr(arena, op.in2) : nullptr; p.fscale = op.fscale;
       p.dst = mptr(arena, op.out); p.dstride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W;
+      if (op.in3.buf >= 0) { p.coarse = cptr(arena, op.in3); p.flow_out = mptr(arena, op.out2); }
       return film_launch_warp(p, s);
     }
     case OP_PACK_FLOW: {
@@ -872,7 +900,8 @@ std::vector<int> wino_candidates(int Cout) {
 }
 
 std::vector<int> wino43_candidates(int Cout) {
-  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_4x64_T12, W43_4x32_T11} : std::vector<int>{W43_4x32_T11};
+  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_4x64_T12, W43_4x32_T11, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11}
+                                            : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11};
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD); }
   return out;
@@ -1013,6 +1042,10 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
         if (h->plans[i]->arena && (victim == h->plans.size() || h->plans[i]->last_use < h->plans[victim]->last_use)) victim = i;
       if (victim == h->plans.size()) break;
       if (h->last_plan == h->plans[victim].get()) h->last_plan = nullptr;
+      // a graph launch of the victim on the caller's stream may still be running (device-resident callers are
+      // asynchronous): its graph, events and workspace must outlive it
+      (void)hipSetDevice(h->device);
+      (void)hipDeviceSynchronize();
       free_plan(h->plans[victim].get());
       h->plans.erase(h->plans.begin() + victim);
       --alive;
@@ -1073,6 +1106,8 @@ std::string plan_json(film_t* h, const Plan& P) {
       << ",\"bytes\":" << op.bytes << ",";
     json_view(o, "in", op.in, P); o << ",";
     json_view(o, "in2", op.in2, P); o << ",";
+    json_view(o, "in3", op.in3, P); o << ",";
+    json_view(o, "out2", op.out2, P); o << ",";
     json_view(o, "out", op.out, P);
     o << ",\"segs\":[";
     for (int k = 0; k < op.nseg; ++k) {
@@ -1412,6 +1447,15 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->plans.clear();
       h->last_plan = nullptr;
       h->opt_splitk = value != 0;
+    }
+  }
+  else if (!strcmp(key, "fuse")) {
+    if ((value != 0) != (h->opt_fuse != 0)) {  // plans carry the op list: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_fuse = value != 0;
     }
   }
   else if (!strcmp(key, "fold2x2")) {

@@ -69,6 +69,8 @@ struct FlowHeadParams {
   const float* b4;
   float* out;         // [M][2]
   int M;
+  const float* add;   // optional [M][2]: the upsampled flow of the coarser level; then sum = out + add is stored too
+  float* sum;         //          [M][2]  (v = residual + v, pyramid_flow_estimator.py:161 - the former flow_add launch)
 };
 
 // 1x1 convolution with a tiny output width (Cout <= 16): flow heads and the RGB head.
@@ -83,6 +85,8 @@ struct ConvPwParams {
   int Cout;
   int leaky;
   int M;              // pixels
+  const float* add;   // Cout == 2 only, optional [M][2]: sum = out + add is stored as well (see FlowHeadParams)
+  float* sum;
 };
 
 // AveragePooling2D(2, 2, 'valid') on a channel slice (util.py:39-40, feature_extractor.py:138-139).
@@ -121,6 +125,11 @@ struct WarpParams {
   float* dst;
   int dstride;
   int NB, H, W;
+  // Fused tf.image.resize(2*v) of the flow estimator (pyramid_flow_estimator.py:155): when `coarse` is set the flow of
+  // this level is bilinear-x2(2 * coarse) ([NB][H/2][W/2][2], same arithmetic as flow_up_kernel) instead of `flow`,
+  // and it is written to flow_out [NB][H][W][2] (C % 4 == 0 launches only) - the former flow_up launch.
+  const float* coarse;
+  float* flow_out;
 };
 
 // Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:
@@ -164,7 +173,9 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                 CONV_TILE_FOLDX3 = 1024 /* conv_foldx3_kernel (precision mode bf16x3, folded upsample + 2x2): shape index =
                                            FoldX3Tile, weights [Cout][chunk][9 (tap, phase) steps][plane][16] bf16 */ };
 // conv_wino43_kernel tiles (CONV_TILE_WINO | CONV_TILE_F43): patch rows x 128 pixels x output channels, wave block TM x TN
-enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2 };   // all 8 waves
+// 0-2: 128-pixel patches, 8 waves, one workgroup per CU; 3-5 ("Q16"): 64-pixel patches (an MFMA row tile = two patch rows x 16
+// quads), 4 waves, 72 / 54 KB of LDS -> two workgroups per CU.  Same k-ordered sums: the autotuner picks freely among them.
+enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_4x64_T21 = 3, W43_Q16_4x64_T12 = 4, W43_Q16_4x32_T11 = 5 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

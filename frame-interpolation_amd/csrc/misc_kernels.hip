@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void conv_pw_kernel(ConvPwParams p) {
     float v = acc[o] + p.bias[o];
     if (p.leaky) v = leaky02(v);
     dst[o] = v;
+    if (COUT == 2 && p.add != nullptr) p.sum[m * 2 + o] = v + p.add[m * 2 + o];   // v = residual + upsampled flow
   }
 }
 
@@ -81,7 +82,12 @@ __global__ __launch_bounds__(256) void flow_head_kernel(FlowHeadParams p) {
     o0 = __builtin_fmaf(hv, wsm[n3 + o * 2], o0);
     o1 = __builtin_fmaf(hv, wsm[n3 + o * 2 + 1], o1);
   }
-  reinterpret_cast<float2*>(p.out)[m] = make_float2(o0 + p.b4[0], o1 + p.b4[1]);
+  const float2 r = make_float2(o0 + p.b4[0], o1 + p.b4[1]);
+  reinterpret_cast<float2*>(p.out)[m] = r;
+  if (p.add != nullptr) {   // v = residual + upsampled flow (pyramid_flow_estimator.py:161)
+    const float2 u = reinterpret_cast<const float2*>(p.add)[m];
+    reinterpret_cast<float2*>(p.sum)[m] = make_float2(r.x + u.x, r.y + u.y);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -208,33 +214,88 @@ __device__ __forceinline__ float lerp3(float tl, float tr, float bl, float br, f
   return ay * (bot - top) + top;
 }
 
+// Flow of output pixel (y, x) of image b.  Either read from p.flow, or - fused resize - computed from the coarser
+// level's flow p.coarse [NB][H/2][W/2][2] exactly as flow_up_kernel does (bilinear x2 of 2*v, half-pixel centres);
+// the caller stores it to p.flow_out once per pixel.
+__device__ __forceinline__ float2 warp_flow_at(const WarpParams& p, int64_t b, int y, int x) {
+  if (p.coarse == nullptr) return reinterpret_cast<const float2*>(p.flow)[(b * p.H + y) * p.W + x];
+  const int h = p.H >> 1, w = p.W >> 1;
+  int ylo, yhi, xlo, xhi;
+  float ty, tx;
+  axis_x2(y, h, ylo, yhi, ty);
+  axis_x2(x, w, xlo, xhi, tx);
+  const float2* img = reinterpret_cast<const float2*>(p.coarse) + b * h * w;
+  const float2 tl = img[(int64_t)ylo * w + xlo], tr = img[(int64_t)ylo * w + xhi];
+  const float2 bl = img[(int64_t)yhi * w + xlo], br = img[(int64_t)yhi * w + xhi];
+  float2 o;
+  {
+    const float a = 2.f * tl.x, bq = 2.f * tr.x, c = 2.f * bl.x, d = 2.f * br.x;
+    const float top = a + (bq - a) * tx, bot = c + (d - c) * tx;
+    o.x = top + (bot - top) * ty;
+  }
+  {
+    const float a = 2.f * tl.y, bq = 2.f * tr.y, c = 2.f * bl.y, d = 2.f * br.y;
+    const float top = a + (bq - a) * tx, bot = c + (d - c) * tx;
+    o.y = top + (bot - top) * ty;
+  }
+  return o;
+}
+
+// grid = (row units / 256, row groups of WARP_ROWS, images).  A thread owns (x, channel group g) for WARP_ROWS
+// consecutive output rows, four rows in flight at a time: the flows of the four rows first, then their sixteen
+// 16-byte corner loads, then the lerps and the four stores - 4x the memory-level parallelism of one row per thread, and
+// the source rows that neighbouring output rows share (fy+1 of row y = fy of row y+1 for smooth flows) are fetched
+// by the same CU within a few hundred cycles instead of by workgroups spread over the eight XCDs' L2s
+// (one row per workgroup: 2.3x over-fetch at the fabric, L2 hit rate 25 %, profiles/r01_pmc_summary.md).
+constexpr int WARP_ROWS = 8;
 __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int G = p.C >> 2;
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
   if (i >= (unsigned)(p.W * G)) return;
   int x, g;
   split_unit(i, G, x, g);
-  const int y = blockIdx.y;
+  const int yb = blockIdx.y * WARP_ROWS;
   const int64_t b = blockIdx.z;
-  const int64_t pix = (b * p.H + y) * p.W + x;
-  const float2 fl = reinterpret_cast<const float2*>(p.flow)[pix];
-  const float qy = (float)y + p.fscale * fl.y;
-  const float qx = (float)x + p.fscale * fl.x;
-  int fy, fx;
-  float ay, ax;
-  warp_axis(qy, p.H, fy, ay);
-  warp_axis(qx, p.W, fx, ax);
-  const float* s00 = p.src + ((b * p.H + fy) * p.W + fx) * p.sstride + g * 4;
-  const float4 tl = *reinterpret_cast<const float4*>(s00);
-  const float4 tr = *reinterpret_cast<const float4*>(s00 + p.sstride);
-  const float4 bl = *reinterpret_cast<const float4*>(s00 + (int64_t)p.W * p.sstride);
-  const float4 br = *reinterpret_cast<const float4*>(s00 + (int64_t)p.W * p.sstride + p.sstride);
-  float4 o;
-  o.x = lerp3(tl.x, tr.x, bl.x, br.x, ax, ay);
-  o.y = lerp3(tl.y, tr.y, bl.y, br.y, ax, ay);
-  o.z = lerp3(tl.z, tr.z, bl.z, br.z, ax, ay);
-  o.w = lerp3(tl.w, tr.w, bl.w, br.w, ax, ay);
-  *reinterpret_cast<float4*>(p.dst + pix * p.dstride + g * 4) = o;
+  const int64_t rowpitch = (int64_t)p.W * p.sstride;
+  const float* const img = p.src + b * p.H * rowpitch + g * 4;
+#pragma unroll
+  for (int k0 = 0; k0 < WARP_ROWS; k0 += 4) {
+    if (yb + k0 >= p.H) break;
+    float ay[4], ax[4];
+    const float* s00[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = min(yb + k0 + j, p.H - 1);     // rows past the end repeat the last one (loads only, no store)
+      const float2 fl = warp_flow_at(p, b, y, x);
+      if (p.flow_out != nullptr && g == 0 && yb + k0 + j < p.H)
+        reinterpret_cast<float2*>(p.flow_out)[(b * p.H + y) * p.W + x] = fl;
+      const float qy = (float)y + p.fscale * fl.y;
+      const float qx = (float)x + p.fscale * fl.x;
+      int fy, fx;
+      warp_axis(qy, p.H, fy, ay[j]);
+      warp_axis(qx, p.W, fx, ax[j]);
+      s00[j] = img + fy * rowpitch + (int64_t)fx * p.sstride;
+    }
+    float4 tl[4], tr[4], bl[4], br[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tl[j] = *reinterpret_cast<const float4*>(s00[j]);
+      tr[j] = *reinterpret_cast<const float4*>(s00[j] + p.sstride);
+      bl[j] = *reinterpret_cast<const float4*>(s00[j] + rowpitch);
+      br[j] = *reinterpret_cast<const float4*>(s00[j] + rowpitch + p.sstride);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int y = yb + k0 + j;
+      if (y >= p.H) break;
+      float4 o;
+      o.x = lerp3(tl[j].x, tr[j].x, bl[j].x, br[j].x, ax[j], ay[j]);
+      o.y = lerp3(tl[j].y, tr[j].y, bl[j].y, br[j].y, ax[j], ay[j]);
+      o.z = lerp3(tl[j].z, tr[j].z, bl[j].z, br[j].z, ax[j], ay[j]);
+      o.w = lerp3(tl[j].w, tr[j].w, bl[j].w, br[j].w, ax[j], ay[j]);
+      *reinterpret_cast<float4*>(p.dst + ((b * p.H + y) * p.W + x) * p.dstride + g * 4) = o;
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void warp_c3_kernel(WarpParams p) {
@@ -243,7 +304,7 @@ __global__ __launch_bounds__(256) void warp_c3_kernel(WarpParams p) {
   const int y = blockIdx.y;
   const int64_t b = blockIdx.z;
   const int64_t pix = (b * p.H + y) * p.W + x;
-  const float2 fl = reinterpret_cast<const float2*>(p.flow)[pix];
+  const float2 fl = warp_flow_at(p, b, y, x);
   const float qy = (float)y + p.fscale * fl.y;
   const float qx = (float)x + p.fscale * fl.x;
   int fy, fx;
@@ -328,11 +389,13 @@ hipError_t film_launch_flow_add(const FlowAddParams& p, hipStream_t s) {
 hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
   const int64_t units = p.C == 3 ? p.W : (int64_t)p.W * (p.C / 4);
   if (units >= (1 << 24) || p.H > 65535 || p.NB > 65535) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB);
+  if (p.coarse != nullptr && ((p.H | p.W) & 1)) return hipErrorInvalidValue;
   if (p.C == 3) {
-    hipLaunchKernelGGL(warp_c3_kernel, grid, dim3(256), 0, s, p);
+    if (p.flow_out != nullptr) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(warp_c3_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL(warp_vec_kernel, grid, dim3(256), 0, s, p);
+    hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB),
+                       dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }

@@ -150,6 +150,8 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             b4 = packed[op['b2_off']:op['b2_off'] + 2]
             hid = fo.conv2d_same(x, w3, b3, 'leaky')
             _view(arena, op['out'], 1, 1, m)[...] = fo.conv2d_same(hid, w4, b4, None)
+            if op.get('out2', {}).get('buf'):       # fused v = residual + upsampled flow
+                _view(arena, op['out2'], 1, 1, m)[...] = _view(arena, op['out'], 1, 1, m) + _view(arena, op['in2'], 1, 1, m)
         elif k == 'conv_pw':
             m = op['n']
             x = np.ascontiguousarray(_view(arena, op['in'], 1, 1, m))
@@ -157,6 +159,9 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             wt = packed[op['w_off']:op['w_off'] + ci * co].reshape(1, 1, ci, co)
             bias = packed[op['b_off']:op['b_off'] + co]
             _view(arena, op['out'], 1, 1, m)[...] = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
+            if op.get('out2', {}).get('buf'):       # flow head: fused v = residual + upsampled flow
+                assert co == 2
+                _view(arena, op['out2'], 1, 1, m)[...] = _view(arena, op['out'], 1, 1, m) + _view(arena, op['in2'], 1, 1, m)
         elif k == 'pool':
             x = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
             _view(arena, op['out'], nb, h // 2, w // 2)[...] = fo.avg_pool2x2(x)
@@ -170,7 +175,13 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             _view(arena, op['out'], 1, 1, m)[...] = a + b
         elif k == 'warp':
             src = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
-            flow = np.ascontiguousarray(_view(arena, op['in2'], nb, h, w))
+            if op.get('in3', {}).get('buf'):        # fused tf.image.resize(2 * v) of the coarser level, stored to out2
+                assert not op['in2']['buf'] and op['out2']['buf']
+                coarse = np.ascontiguousarray(_view(arena, op['in3'], nb, h // 2, w // 2))
+                flow = fo.resize_bilinear(np.float32(2) * coarse, (h, w))
+                _view(arena, op['out2'], nb, h, w)[...] = flow
+            else:
+                flow = np.ascontiguousarray(_view(arena, op['in2'], nb, h, w))
             _view(arena, op['out'], nb, h, w)[...] = fo.warp(src, np.float32(op['fscale']) * flow)
         elif k == 'pack_flow':
             m = op['n']

@@ -1,0 +1,176 @@
+"""GPU parity on the BASELINE.json configurations themselves, DEFAULT planner options (the kernel families the
+headline number runs on): HIP engine through the C-ABI vs (a) the CPU oracle on the full tensors and (b) the
+committed vectors produced by the reference's own graph code (tests/golden/ref_*.npz, tools/make_ref_golden.py;
+tf_*.npz when a TensorFlow-made set exists).  Inputs are structured frames with >= 8 px motion (tests/inputs.py)
+and the reference's photos.  max|delta| per stage is printed."""
+import os
+
+import numpy as np
+import pytest
+
+import golden_util as G
+import inputs as TI
+from test_gpu_parity import _check_stages, _engine
+
+from eval.interpolator import Interpolator as _REAL_INTERPOLATOR   # (one test monkeypatches the module attribute)
+
+pytestmark = pytest.mark.gpu
+
+IMAGE_TOL = 1e-3          # north_star: |delta| < 1e-3 fp32 per pixel
+HALF = np.full((1,), 0.5, np.float32)
+
+
+@pytest.fixture(scope='module')
+def published():
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    eng = _engine(PUBLISHED, w)
+    yield PUBLISHED, w, eng
+    eng.close()
+
+
+def _interp(eng, w, **kw):
+    """eval.interpolator.Interpolator sharing the module's engine (construction repacks 137.7 MB of weights)."""
+    it = _REAL_INTERPOLATOR.__new__(_REAL_INTERPOLATOR)
+    it._options, it._engine = eng.options, eng
+    it._align, it._block_shape = kw.get('align') or None, kw.get('block_shape') or None
+    return it
+
+
+def test_tile_960x576_stage_by_stage(published):
+    """One tile of the headline workload (a 960x540 patch padded to 960x576): every pyramid level's features,
+    residual flows, flows, aligned pyramid and the image, default plan (F(4,3) on the 960/480/240/120-wide levels,
+    F(2,3) on the 60-wide one, split-K on 30x18 and 15x9)."""
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    x0, x1 = TI.frame_pair(1, 1080, 1920, seed=2, shift=(11, -17), fg_shift=(-9, 21))
+    p0, _ = fo.pad_to_align(x0[:, :540, :960], 64)
+    p1, _ = fo.pad_to_align(x1[:, :540, :960], 64)
+    assert p0.shape == (1, 576, 960, 3)
+    plan = eng.plan(1, 576, 960)
+    fams = sorted({(o.get('tile', 0) & 256, o.get('tile', 0) & 2048) for o in plan['ops'] if o.get('kind') == 'conv_mfma'})
+    print('conv families in the default plan (wino bit, F(4,3) bit):', fams)
+    _check_stages(eng, opt, w, p0, p1)
+
+
+def test_1080p_2x2_tiled_frame(published):
+    """BASELINE configs[2], the config the metric is quoted on: Interpolator('', align=64, block_shape=[2,2]) on a
+    1920x1080 pair (eval/interpolator_test.py:73-99, eval/interpolator.py:192-206)."""
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    g, prov = G.load('1080p')
+    x0, x1 = TI.frame_pair(1, 1080, 1920, seed=2, shift=(11, -17), fg_shift=(-9, 21))
+    G.check_inputs(g, x0, x1)
+    got = _interp(eng, w, align=64, block_shape=[2, 2])(x0, x1, HALF)
+    d_gold = G.diff(g, 'image', got)
+    want = fo.OracleInterpolator(w, align=64, block_shape=[2, 2])(x0, x1, HALF)
+    d_or = float(np.abs(got - want).max())
+    print(f'1080p 2x2: hip vs oracle max|d| {d_or:.3e} psnr {fo.psnr(got, want):.1f} dB; hip vs {prov} golden {d_gold:.3e}')
+    assert got.shape == (1, 1080, 1920, 3) and d_or < IMAGE_TOL and d_gold < IMAGE_TOL
+
+
+def test_photos_1024x768(published):
+    """BASELINE configs[0]: photos/one.png + two.png (copies under tests/golden/), t = 0.5, align 64."""
+    from eval import util
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    g, prov = G.load('photos')
+    a = util.read_image(os.path.join(G.GOLDEN, 'photo_one.png'))
+    b = util.read_image(os.path.join(G.GOLDEN, 'photo_two.png'))
+    G.check_inputs(g, a, b)
+    got = _interp(eng, w, align=64, block_shape=[1, 1])(a[None], b[None], HALF)
+    d_gold = G.diff(g, 'image', got)
+    want = fo.OracleInterpolator(w, align=64)(a[None], b[None], HALF)
+    d_or = float(np.abs(got - want).max())
+    du8 = int(np.abs(util.to_uint8(got[0])[::4, ::4].astype(np.int32) - g['image_u8.s4'].astype(np.int32)).max())
+    print(f'photos: hip vs oracle max|d| {d_or:.3e} psnr {fo.psnr(got, want):.1f} dB; hip vs {prov} golden {d_gold:.3e}; uint8 {du8}')
+    assert d_or < IMAGE_TOL and d_gold < IMAGE_TOL and du8 <= 1
+
+
+def test_vimeo_batch_of_8(published):
+    """BASELINE configs[3]: eight 448x256 pairs in one call."""
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    g, prov = G.load('vimeo')
+    x0, x1 = TI.frame_pair(8, 256, 448, seed=3)
+    G.check_inputs(g, x0, x1)
+    got = _interp(eng, w, align=64)(x0, x1, np.full((8,), 0.5, np.float32))
+    d_gold = G.diff(g, 'image', got)
+    want = fo.OracleInterpolator(w, align=64)(x0, x1, None)
+    d_or = float(np.abs(got - want).max())
+    print(f'vimeo b8: hip vs oracle max|d| {d_or:.3e}; hip vs {prov} golden {d_gold:.3e}')
+    assert d_or < IMAGE_TOL and d_gold < IMAGE_TOL
+
+
+def test_256_against_reference_graph_taps(published):
+    """BASELINE configs[1] with the structured pair: image, warped images and all flow pyramids of the model's aux
+    dictionary (interpolator.py:191-199) vs the reference-graph golden."""
+    opt, w, eng = published
+    g, prov = G.load('256')
+    x0, x1 = TI.frame_pair(1, 256, 256, seed=1)
+    G.check_inputs(g, x0, x1)
+    aux = eng.forward_with_aux(x0, x1)
+    rep = {'image': float(np.abs(aux['image'] - g['image_full']).max()),
+           'image_vs_f64_truth': float(np.abs(aux['image'] - g['image_f64']).max()) if 'image_f64' in g.files else 0.0,
+           'x0_warped': G.diff(g, 'x0_warped', aux['x0_warped']), 'x1_warped': G.diff(g, 'x1_warped', aux['x1_warped'])}
+    for d in ('forward', 'backward'):
+        for l, v in enumerate(aux[f'{d}_flow_pyramid']):
+            rep[f'{d}_flow{l}'] = G.diff(g, f'{d}_flow{l}', v)
+        for l, v in enumerate(aux[f'{d}_residual_flow_pyramid']):
+            rep[f'{d}_res{l}'] = G.diff(g, f'{d}_residual_flow{l}', v)
+    print(prov, {k: float(f'{v:.1e}') for k, v in rep.items()})
+    assert max(rep.values()) < 2e-4 and rep['image'] < IMAGE_TOL
+
+
+def test_recursion_T2_tiled_against_reference_order(published, monkeypatch):
+    """T = 2 recursion of a 2x1-tiled 200x176 pair.  (a) the CLI's default path - device-resident
+    breadth-first driver behind eval/util.interpolate_recursively_from_memory; (b) the reference-order depth-first
+    host generator; both vs the frames the reference's own eval/util.py produced (golden) incl. write_image's uint8
+    rounding, and vs the oracle driven by the reference-order generator."""
+    from eval import util
+    from oracle import film_oracle as fo
+    opt, w, eng = published
+    g, prov = G.load('recursive')
+    x0, x1 = TI.frame_pair(1, 200, 176, seed=4, shift=(6, -8), fg_shift=(-4, 9))
+    G.check_inputs(g, x0, x1)
+    it = _interp(eng, w, align=64, block_shape=[2, 1])
+    dev_frames = np.stack(list(util.interpolate_recursively_from_memory([x0[0], x1[0]], 2, it)))
+    monkeypatch.setenv('FILM_HOST_RECURSION', '1')
+    host_frames = np.stack(list(util.interpolate_recursively_from_memory([x0[0], x1[0]], 2, it)))
+    monkeypatch.delenv('FILM_HOST_RECURSION')
+    assert dev_frames.shape == host_frames.shape == (5, 200, 176, 3)
+    assert np.array_equal(dev_frames, host_frames), 'breadth-first device recursion must be bit-identical'
+    orc = np.stack(list(util.interpolate_recursively_from_memory(
+        [x0[0], x1[0]], 2, fo.OracleInterpolator(w, align=64, block_shape=[2, 1]))))
+    d_or = float(np.abs(dev_frames - orc).max())
+    d_gold = float(np.abs(dev_frames - g['frames']).max())
+    u8 = np.stack([util.to_uint8(f) for f in dev_frames])
+    du8 = int(np.abs(u8.astype(np.int32) - g['frames_u8'].astype(np.int32)).max())
+    print(f'recursion T=2: hip vs oracle {d_or:.3e}; hip vs {prov} golden {d_gold:.3e}; uint8 {du8}')
+    assert d_or < IMAGE_TOL and d_gold < IMAGE_TOL and du8 <= 1
+
+
+def test_interpolator_cli_writes_reference_frames(published, tmp_path, monkeypatch):
+    """eval.interpolator_cli end to end on a directory of two PNGs (device recursion by default): frame files and
+    their pixels vs the host depth-first path."""
+    from eval import interpolator_cli as cli
+    from eval import util
+    from eval import interpolator as interpolator_lib
+    opt, w, eng = published
+    x0, x1 = TI.frame_pair(1, 96, 160, seed=6, shift=(4, -6), fg_shift=(-3, 5))
+    d = tmp_path / 'clip'
+    d.mkdir()
+    util.write_image(str(d / 'a_1.png'), x0[0])
+    util.write_image(str(d / 'a_2.png'), x1[0])
+    monkeypatch.setattr(interpolator_lib, 'Interpolator',
+                        lambda model_path, align, block_shape, precision=0: _interp(eng, w, align=align, block_shape=block_shape))
+    cli.main(['--pattern', str(tmp_path / '*'), '--times_to_interpolate', '2', '--block_height', '1', '--block_width', '2'])
+    files = sorted(os.listdir(d / 'interpolated_frames'))
+    assert files == [f'frame_{i:03d}.png' for i in range(5)]
+    a, b = util.read_image(str(d / 'a_1.png')), util.read_image(str(d / 'a_2.png'))
+    monkeypatch.setenv('FILM_HOST_RECURSION', '1')
+    want = list(util.interpolate_recursively_from_memory([a, b], 2, _interp(eng, w, align=64, block_shape=[1, 2])))
+    for f, wnt in zip(files, want):
+        got = util.read_image(str(d / 'interpolated_frames' / f))
+        assert np.array_equal(util.to_uint8(wnt), (got * 255 + 0.5).astype(np.uint8)), f

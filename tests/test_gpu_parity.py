@@ -224,7 +224,7 @@ def test_film_interpolate_equals_numpy_pad_patch_path(published):
         eng.interpolate_frames(x0, x1, align=64, block_shape=[4, 2])   # 150 % 4 != 0
 
 
-def test_breadth_first_device_recursion_equals_reference_order(published):
+def test_breadth_first_device_recursion_equals_reference_order(published, monkeypatch):
     """film_hip.recursive (one batched call per depth, frames resident in HBM) vs the reference's depth-first
     generator through the numpy Interpolator (eval/util.py:62-91): same frames, same order, same bits."""
     import torch
@@ -236,7 +236,9 @@ def test_breadth_first_device_recursion_equals_reference_order(published):
     rng = np.random.default_rng(37)
     frames = [rng.random((72, 100, 3), dtype=np.float32) for _ in range(3)]
     host_it = Interpolator('', align=64, block_shape=[2, 2], weights=w)
+    monkeypatch.setenv('FILM_HOST_RECURSION', '1')     # the reference-order host generator, not the device driver
     want = list(util.interpolate_recursively_from_memory(frames, 2, host_it))
+    monkeypatch.delenv('FILM_HOST_RECURSION')
     dev_it = DeviceInterpolator(eng, align=64, block_shape=[2, 2])
     got = [f.cpu().numpy() for f in interpolate_recursively([torch.from_numpy(f).cuda() for f in frames], 2, dev_it)]
     assert len(got) == len(want) == 2 * 4 + 1
