@@ -20,21 +20,26 @@
 //     are not in phase, and twice as many (half-size) workgroups per layer for the tails of the 120-wide level;
 //   * K chunks of 8 channels; the (TH+2) halo rows of a chunk are transformed ONCE on the way into LDS, image
 //     [halo row][nu 6][quad QW][8 channels] (32-byte rows, K-halves swapped on bit 3 of the quad: conflict-free b128);
-//   * the six nu planes are independent GEMMs: wave half h accumulates nu = 3h .. 3h+2 for its TM rows x TN channel tiles
-//     (TM*TN*3 accumulator tiles per wave) and the halves swap partial output sums through LDS in the epilogue;
+//   * the six nu planes are independent GEMMs.  NH = 2: wave half h accumulates nu = 3h .. 3h+2 for its TM rows x TN channel
+//     tiles (TM*TN*3 accumulator tiles per wave) and the halves swap partial output sums through LDS in the epilogue.
+//     NH = 1: a wave accumulates all six planes of ONE 32x32 tile (TM = TN = 1, the same 96 accumulator registers) and
+//     forms y0..y3 in registers - no exchange, no epilogue barriers (12 instead of 9 fragment reads per 24 MFMAs);
+//     the sums are written in the same order either way: every tile shape gives the same bits;
 //   * weights [Cout][chunk][dy][nu][8] (192 contiguous bytes per dy stage and channel) through a 3-slot LDS ring
 //     (slot = dy), requested three stages ahead in registers; one barrier per dy stage = 3*4*TM*TN MFMAs per wave;
 //   * fragment registers triple buffered over the nu steps: the ds_reads of step s+1 are issued before the MFMAs of s.
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W43_F_SETPRIO = 64 };   // FLAGS bit (experiments): raise the wave priority around the MFMA groups
+enum { W43_F_SETPRIO = 64 };   // FLAGS bit (experiments): raise the wave priority around the MFMA groups (measured: -1..-3 %)
 
-template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32>
-__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) void conv_wino43_kernel(ConvParams p) {
+template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
+__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH) void conv_wino43_kernel(ConvParams p) {
   constexpr int RPT = 32 / QW;                 // patch rows per 32-quad MFMA tile
   constexpr int MT = TH / RPT;                 // MFMA row tiles per patch; TM of them per wave
-  constexpr int RG = MT / TM, NG = BN / (32 * TN), PW = RG * NG, NW = 2 * PW, NT = NW * 64;
+  constexpr int NU = 6 / NH;                   // nu planes per wave
+  constexpr int RG = MT / TM, NG = BN / (32 * TN), PW = RG * NG, NW = NH * PW, NT = NW * 64;
+  static_assert(NH == 2 || (NH == 1 && TM == 1 && TN == 1), "nu split");
   constexpr int HR = TH + 2;
   constexpr int A_PLANE = QW * 8;              // floats of one nu plane of a halo row
   constexpr int A_STAGE = HR * 6 * A_PLANE;    // floats: [hy][nu][quad][8]
@@ -46,7 +51,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) voi
   constexpr int PXW = 4 * QW;                  // patch width in pixels
   static_assert(QW == 32 || QW == 16, "quads per patch row");
   static_assert(TH % RPT == 0 && MT % TM == 0 && BN % (32 * TN) == 0 && ITEMS <= NT && 2 * ITEMS > NT, "bad tile");
-  static_assert(2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + 3 * B_STAGE, "exchange buffer does not fit");
+  static_assert(NH == 1 || 2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + 3 * B_STAGE, "exchange buffer does not fit");
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
   extern __shared__ __attribute__((aligned(1024))) float smem[];  // [A0][A1][B ring x3]
@@ -164,11 +169,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) voi
       if (NT * (i + 1) <= BU || blds[i] >= 0) *reinterpret_cast<bf4*>(Bs + blds[i]) = breg[buf][i];
   };
 
-  f32x16 acc[TM][3][TN];   // [row][nu - 3h][channel tile]
+  f32x16 acc[TM][NU][TN];   // [row][nu - NU*h][channel tile]
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int v = 0; v < 3; ++v)
+    for (int v = 0; v < NU; ++v)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -180,17 +185,17 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) voi
   const int wm = rg * TM;                    // first MFMA row tile of this wave
   const int lrow = l31 / QW, lq = l31 % QW;  // lane -> (patch row inside the tile, quad)
   const int swb = (lq >> 3) & 1;
-  const int a_ad = (((wm * RPT + lrow) * 6 + 3 * h) * QW + lq) * 2 + (half ^ swb);     // + ((mt * RPT + dy) * 6 + j) * QW * 2, stage
-  const int b_ad = 2 * A_STAGE4 + (3 * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
+  const int a_ad = (((wm * RPT + lrow) * 6 + NU * h) * QW + lq) * 2 + (half ^ swb);     // + ((mt * RPT + dy) * 6 + j) * QW * 2, stage
+  const int b_ad = 2 * A_STAGE4 + (NU * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
   int a_cur = a_ad;
 
-  bf4 fa[3][TM], fb[3][TN];   // [nu step j][tile]
+  bf4 fa[3][TM], fb[3][TN];   // [nu step j mod 3][tile]: triple buffered
   auto fetch = [&](auto dy_c, auto j_c, int a_base) {
     constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) fa[J][mt] = smem4[a_base + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
+    for (int mt = 0; mt < TM; ++mt) fa[J % 3][mt] = smem4[a_base + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) fb[J][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
+    for (int nt = 0; nt < TN; ++nt) fb[J % 3][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
   };
   auto compute = [&](auto j_c) {
     constexpr int J = decltype(j_c)::value;
@@ -201,19 +206,19 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) voi
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
-          acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J][mt][k], fb[J][nt][k], acc[mt][J][nt], 0, 0, 0);
+          acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J % 3][mt][k], fb[J % 3][nt][k], acc[mt][J][nt], 0, 0, 0);
     if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
   setup_seg();
-  load_item();
-  store_item(0);
+  load_item();        // every request of the prologue first, then the stores: one load latency instead of three
   load_b(0, 0);
-  store_b(0, 0);
-  load_b(1, 0);
-  store_b(1, 0);
+  load_b(1, 1);
   load_b(2, 2);
+  store_item(0);
+  store_b(0, 0);
+  store_b(1, 1);
   next_chunk(1);
   __syncthreads();
   fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur);
@@ -229,8 +234,16 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) voi
       compute(std::integral_constant<int, 0>{});
       fetch(dy_c, std::integral_constant<int, 2>{}, a_cur);
       compute(std::integral_constant<int, 1>{});
+      if constexpr (NU == 6) {
+        fetch(dy_c, std::integral_constant<int, 3>{}, a_cur);
+        compute(std::integral_constant<int, 2>{});
+        fetch(dy_c, std::integral_constant<int, 4>{}, a_cur);
+        compute(std::integral_constant<int, 3>{});
+        fetch(dy_c, std::integral_constant<int, 5>{}, a_cur);
+        compute(std::integral_constant<int, 4>{});
+      }
       fetch(std::integral_constant<int, (DY + 1) % 3>{}, std::integral_constant<int, 0>{}, DY == 2 ? a_next : a_cur);
-      compute(std::integral_constant<int, 2>{});
+      compute(std::integral_constant<int, NU - 1>{});
       __builtin_amdgcn_sched_barrier(0);
       store_b((DY + 2) % 3, (DY + 2) % 3);
       if constexpr (DY == 1) store_item(a_stage ^ 1);
@@ -297,16 +310,43 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128) voi
       }
     }
   };
-  if (h == 0) finish(std::integral_constant<int, 0>{});
-  else finish(std::integral_constant<int, 1>{});
+  if constexpr (NH == 2) {
+    if (h == 0) finish(std::integral_constant<int, 0>{});
+    else finish(std::integral_constant<int, 1>{});
+  } else {
+    // all six planes in this wave: the same sums, in the same order, as the two-half exchange above
+    const int n = n0 + ng * 32 + l31;
+    const float bv = p.bias[n];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int y = y0 + wm * RPT + mrow / QW;
+      if (y >= p.H) continue;
+      const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+      const int x = x0 + 4 * (mrow % QW);
+      const float m0 = acc[0][0][0][r], m1 = acc[0][1][0][r], m2 = acc[0][2][0][r], m3 = acc[0][3][0][r], m4 = acc[0][4][0][r],
+                  m5 = acc[0][5][0][r];
+      float v[4];
+      v[0] = ((m0 + m1) + m2) + (m3 + m4);
+      v[1] = (m1 - m2) + 2.f * (m3 - m4);
+      v[2] = (m1 + m2) + 4.f * (m3 + m4);
+      v[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float o = v[j] + bv;
+        if (p.leaky) o = o > 0.f ? o : 0.2f * o;
+        if (x + j < p.W) p.out[(rowbase + x + j) * p.ostride + n] = o;
+      }
+    }
+  }
 }
 
-template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32>
+template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
 hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (2 * (size_t)(TH + 2) * 6 * QW * 8 + 3 * 6 * (size_t)BN * 8) * sizeof(float);
-  constexpr int NT = ((TH * QW / 32) / TM) * (BN / (32 * TN)) * 128;
+  constexpr int NT = ((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH;
   static_assert(lds <= 160 * 1024, "LDS");
-  auto kern = conv_wino43_kernel<TH, BN, TM, TN, FLAGS, QW>;
+  auto kern = conv_wino43_kernel<TH, BN, TM, TN, FLAGS, QW, NH>;
   if constexpr (lds > 64 * 1024) {
     static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
     int dev = 0;

@@ -164,7 +164,7 @@ struct film_handle {
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
-  int opt_fuse = 1;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
+  int opt_fuse = 3;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
@@ -628,7 +628,7 @@ struct Planner {
       if (l == L - 1) {
         sb.v = view(feat[l], 0, 0, fc[l]); sb.boff = B; sb.bmod = N2;  // the other image's features
       } else {
-        if (!h->opt_fuse) {
+        if (!(h->opt_fuse & 1)) {
           OpDesc up;
           up.kind = OP_FLOW_UP; up.tag = tg + ":resize2x";
           up.in = view(v[l + 1], 0, 0, 2); up.out = view(vup[l], 0, 0, 2);
@@ -639,7 +639,7 @@ struct Planner {
         for (int d = 0; d < 2; ++d) {  // warp the OTHER image's features with this direction's flow
           warp(tg + ":warp_d" + std::to_string(d), view(feat[l], (1 - d) * B, 0, fc[l]), view(vup[l], d * B, 0, 2),
                view(warped[l], d * B, 0, fc[l]), B, Hl, Wl, 1.f);
-          if (h->opt_fuse) {
+          if (h->opt_fuse & 1) {
             // tf.image.resize(2 * v) (pyramid_flow_estimator.py:155) inside the warp: the flow of this level is computed
             // from the coarser level's v by every thread of a pixel and stored once (to vup, which v = res + up reads)
             OpDesc& w = P->ops.back();
@@ -666,7 +666,7 @@ struct Planner {
         SegDesc s; s.v = cur;
         conv(tg, l3, {s}, hid, N2, Hl, Wl, true);
         conv_pw(tg, l4, hid, view(res[l], 0, 0, 2), (int64_t)N2 * Hl * Wl, false);
-        if (h->opt_fuse && l < L - 1) {   // v = res + up in the head's epilogue
+        if ((h->opt_fuse & 2) && l < L - 1) {   // v = res + up in the head's epilogue
           OpDesc& pw = P->ops.back();
           pw.tag += "+v=res+up";
           pw.in2 = view(vup[l], 0, 0, 2); pw.out2 = view(v[l], 0, 0, 2);
@@ -679,13 +679,13 @@ struct Planner {
         op.in = cur; op.out = view(res[l], 0, 0, 2); op.n = (int64_t)N2 * Hl * Wl; op.Ctot = nf;
         op.w_off = L3.w_off; op.b_off = L3.b_off; op.w2_off = L4.w_off; op.b2_off = L4.b_off;
         op.flops = 2.0 * op.n * (nf * 16 + 16 * 2); op.bytes = 4.0 * op.n * (nf + 2);
-        if (h->opt_fuse && l < L - 1) {
+        if ((h->opt_fuse & 2) && l < L - 1) {
           op.tag += "+v=res+up";
           op.in2 = view(vup[l], 0, 0, 2); op.out2 = view(v[l], 0, 0, 2);
         }
         P->ops.push_back(op);
       }
-      if (l < L - 1 && !h->opt_fuse) {
+      if (l < L - 1 && !(h->opt_fuse & 2)) {
         OpDesc ad;
         ad.kind = OP_FLOW_ADD; ad.tag = tg + ":v=res+up";
         ad.in = view(res[l], 0, 0, 2); ad.in2 = view(vup[l], 0, 0, 2); ad.out = view(v[l], 0, 0, 2);
@@ -900,7 +900,7 @@ std::vector<int> wino_candidates(int Cout) {
 }
 
 std::vector<int> wino43_candidates(int Cout) {
-  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_4x64_T12, W43_4x32_T11, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11}
+  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_4x64_T12, W43_4x32_T11, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11, W43_Q16_4x64_N1}
                                             : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11};
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD); }
@@ -1450,12 +1450,12 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "fuse")) {
-    if ((value != 0) != (h->opt_fuse != 0)) {  // plans carry the op list: drop them
+    if ((int)(value & 3) != h->opt_fuse) {  // plans carry the op list: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
       h->plans.clear();
       h->last_plan = nullptr;
-      h->opt_fuse = value != 0;
+      h->opt_fuse = (int)(value & 3);
     }
   }
   else if (!strcmp(key, "fold2x2")) {
@@ -1685,14 +1685,41 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
         le = hipEventRecord(event_of(nops), h->stream);
         if (le == hipSuccess) le = hipStreamWaitEvent(h->stream2, event_of(nops), 0);
       }
+      long prev_in_lane[2] = {-1, -1};
+      // Relay edges.  When lane X waits for the LAST op p of lane Y, the next op q of lane Y additionally waits for an
+      // event recorded on X behind that waiter.  By stream order q already follows p, the captured graph has the edge
+      // p -> q (checked with hipGraphGetEdges, tools/experiments/capture_edges.hip), and still: with the flow upsample
+      // fused into the warps AND v = res + up fused into the heads, the replayed graph ran the level-4 t = 0.5 warps
+      // (q) on the PREVIOUS forward's v4 - deterministically, on every shape (ROCm 7.2; tools/dbg_graph_race.py; the
+      // eager path and every other fuse setting were clean).  With the extra parent the replay is bit-identical to the
+      // eager launches on changing inputs (tests/test_gpu_parity.py::test_graph_replay_on_changing_inputs).
+      hipEvent_t relay[2] = {nullptr, nullptr};
+      std::vector<hipEvent_t> relay_pool;
       for (size_t i = 0; i < nops && le == hipSuccess; ++i) {
         const OpDesc& op = P->ops[i];
-        hipStream_t ls = (two_lanes && op.lane == 1) ? h->stream2 : h->stream;
-        if (two_lanes)
-          for (int d : op.xdeps) { le = hipStreamWaitEvent(ls, event_of((size_t)d), 0); if (le != hipSuccess) break; }
+        const int lane = (two_lanes && op.lane == 1) ? 1 : 0;
+        hipStream_t ls = lane ? h->stream2 : h->stream;
+        bool waited_on_last = false;
+        if (two_lanes) {
+          for (int d : op.xdeps) {
+            le = hipStreamWaitEvent(ls, event_of((size_t)d), 0);
+            if (le != hipSuccess) break;
+            if ((long)d == prev_in_lane[1 - lane]) waited_on_last = true;
+          }
+          if (le == hipSuccess && relay[lane]) { le = hipStreamWaitEvent(ls, relay[lane], 0); relay[lane] = nullptr; }
+        }
         if (le == hipSuccess) le = launch_op(op, P->arena, h->packed_dev, ls);
         if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
+        if (le == hipSuccess && two_lanes && waited_on_last && !relay[1 - lane]) {
+          hipEvent_t e = nullptr;
+          (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+          relay_pool.push_back(e);
+          le = hipEventRecord(e, ls);
+          relay[1 - lane] = e;
+        }
+        prev_in_lane[lane] = (long)i;
       }
+      for (hipEvent_t e : relay_pool) P->lane_ev.push_back(e);   // destroyed with the plan
       if (two_lanes && le == hipSuccess) {
         le = hipEventRecord(event_of(nops + 1), h->stream2);
         if (le == hipSuccess) le = hipStreamWaitEvent(h->stream, event_of(nops + 1), 0);

@@ -175,7 +175,8 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
 // conv_wino43_kernel tiles (CONV_TILE_WINO | CONV_TILE_F43): patch rows x 128 pixels x output channels, wave block TM x TN
 // 0-2: 128-pixel patches, 8 waves, one workgroup per CU; 3-5 ("Q16"): 64-pixel patches (an MFMA row tile = two patch rows x 16
 // quads), 4 waves, 72 / 54 KB of LDS -> two workgroups per CU.  Same k-ordered sums: the autotuner picks freely among them.
-enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_4x64_T21 = 3, W43_Q16_4x64_T12 = 4, W43_Q16_4x32_T11 = 5 };
+enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_4x64_T21 = 3, W43_Q16_4x64_T12 = 4, W43_Q16_4x32_T11 = 5,
+                  W43_Q16_4x64_N1 = 6 /* a wave owns all six nu planes of one 32x32 tile: no epilogue exchange */ };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

@@ -435,3 +435,30 @@ def test_autotuned_tiles_do_not_change_results(published):
     ref = plain.forward(x0, x1)
     plain.close()
     assert np.array_equal(tuned, ref)
+
+
+@pytest.mark.parametrize('fuse', [3, 0])
+def test_graph_replay_on_changing_inputs(published, fuse):
+    """The two-lane hipGraph replay vs eager launches with inputs that CHANGE every forward (a missing edge or a stale
+    read in the replayed graph shows up as the previous forward's data; equal inputs would hide it): image and every
+    aligned-pyramid level bit-identical, several shapes, default fusion options and none."""
+    from film_hip.engine import FilmEngine
+    opt, w, _ = published
+    eg = FilmEngine(opt, device=0)
+    eg.set_weights(w)
+    eg.set_option('fuse', fuse)
+    ee = FilmEngine(opt, device=0)
+    ee.set_weights(w)
+    ee.set_option('fuse', fuse)
+    ee.set_option('graph', 0)
+    for (b, h, wd) in ((1, 64, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320)):
+        for it in range(3):
+            rng = np.random.default_rng(1000 * h + it)
+            x0 = rng.random((b, h, wd, 3), dtype=np.float32)
+            x1 = rng.random((b, h, wd, 3), dtype=np.float32)
+            a, c = eg.forward(x0, x1), ee.forward(x0, x1)
+            assert np.array_equal(a, c), (b, h, wd, it, float(np.abs(a - c).max()))
+            for l in range(opt.fusion_pyramid_levels):
+                assert np.array_equal(eg.tap(f'aligned{l}'), ee.tap(f'aligned{l}')), (b, h, wd, it, l)
+    eg.close()
+    ee.close()

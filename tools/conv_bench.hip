@@ -65,6 +65,7 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 #define XA(TH, BN, TM, TN, FL) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, FL>}
 #define F43(TH, BN, TM, TN) {"wino43 " #TH "x128x" #BN " t" #TM "x" #TN " f4", TH * 128, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, 4>}
 #define F43Q(TH, BN, TM, TN, FL) {"wino43 q16 " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, FL, 16>}
+#define F43N(TH, BN, FL) {"wino43 q16 nh1 " #TH "x64x" #BN " t1x1 f" #FL, TH * 64, BN, 8, 7, conv_wino43_launch<TH, BN, 1, 1, FL, 16, 1>}
 #define F43F(TH, BN, TM, TN, FL) {"wino43 " #TH "x128x" #BN " t" #TM "x" #TN " f" #FL, TH * 128, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, FL>}
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
@@ -72,7 +73,8 @@ static Variant variants[] = {
     W(4, 128, 4, 2), W(4, 64, 4, 1), W(4, 64, 4, 2), W(2, 128, 2, 2), W(4, 32, 4, 1),
     W8(4, 64, 4, 2), W8(4, 128, 4, 2), W8(4, 128, 4, 4), W8(4, 32, 4, 1), W8(8, 64, 8, 2), W8(8, 32, 8, 1), W8(2, 64, 2, 2),
     F43(4, 64, 1, 2), F43(4, 64, 2, 1), F43(4, 32, 1, 1), F43F(4, 64, 2, 1, 68), F43F(4, 64, 2, 1, 0),
-    F43Q(4, 64, 2, 1, 4), F43Q(4, 64, 1, 2, 4), F43Q(4, 32, 1, 1, 4), F43Q(4, 64, 2, 1, 68), F43Q(4, 64, 2, 1, 0), F43Q(8, 64, 2, 1, 4),
+    F43Q(4, 64, 2, 1, 4), F43Q(4, 64, 1, 2, 4), F43Q(4, 32, 1, 1, 4), F43Q(4, 64, 2, 1, 0),
+    F43N(4, 64, 4), F43N(4, 64, 0),
     X(4, 128, 2, 2), XA(4, 128, 2, 2, 1028), XA(4, 128, 2, 2, 2052), XA(4, 64, 2, 1, 1028), XA(4, 64, 2, 1, 2052), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
     S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 128, 2, 2, 3), S(16, 128, 4, 2, 3), S(16, 64, 4, 1, 3), S(8, 64, 2, 1, 3), S(16, 128, 4, 1, 3), S(8, 64, 4, 1, 3), S(4, 128, 2, 2, 3), S(8, 32, 4, 1, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),

@@ -1,0 +1,25 @@
+"""Graph replay (two lanes) vs eager launches on inputs that CHANGE every forward: any ordering / visibility hole in the
+replayed graph shows up as stale data.  Prints max|diff| per shape and forward."""
+import sys, numpy as np
+sys.path[:0] = ['/root/repo', '/root/repo/frame-interpolation_amd', '/root/repo/tests']
+from film_hip import weights as W
+from film_hip.options import PUBLISHED
+from film_hip.engine import FilmEngine
+w = W.make_synthetic_weights(PUBLISHED, seed=0)
+fuse = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+eg = FilmEngine(PUBLISHED, device=0); eg.set_weights(w); eg.set_option('fuse', fuse)
+ee = FilmEngine(PUBLISHED, device=0); ee.set_weights(w); ee.set_option('fuse', fuse); ee.set_option('graph', 0)
+for (b, h, wd) in ((1, 64, 64), (1, 128, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320), (1, 576, 960)):
+    worst = 0.0
+    for it in range(4):
+        rng = np.random.default_rng(100 * h + it)
+        x0 = rng.random((b, h, wd, 3), dtype=np.float32)
+        x1 = rng.random((b, h, wd, 3), dtype=np.float32)
+        a = eg.forward(x0, x1); c = ee.forward(x0, x1)
+        d = float(np.abs(a - c).max())
+        taps = {}
+        for l in range(5):
+            taps[l] = float(np.abs(eg.tap(f'aligned{l}') - ee.tap(f'aligned{l}')).max())
+        worst = max(worst, d)
+        print(f'{b}x{h}x{wd} forward {it}: image {d:.3e} aligned {[f"{v:.1e}" for v in taps.values()]}', flush=True)
+print('done')
