@@ -31,7 +31,15 @@
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W43_F_SETPRIO = 64 };   // FLAGS bit (experiments): raise the wave priority around the MFMA groups (measured: -1..-3 %)
+enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priority around the MFMA groups (measured: -1..-3 %)
+       // timing ablations (tools/conv_bench.hip only; results are wrong on purpose):
+       W43_DBG_NOA = 256,      // no activation loads / transforms / LDS stores inside the K loop
+       W43_DBG_NOB = 512,      // no weight loads / LDS stores inside the K loop
+       W43_DBG_NOBAR = 1024,   // no barrier inside the K loop
+       W43_DBG_NOFRAG = 2048,
+       W43_DBG_NOALOAD = 4096, // activation loads skipped, transform + LDS stores of stale registers kept
+       W43_DBG_NOASTORE = 8192,// activation loads kept, transform + LDS stores skipped
+       W43_F_PF2 = 32768 };    // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
 __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH) void conv_wino43_kernel(ConvParams p) {
@@ -123,23 +131,26 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
     blds[i] = slot ? nu * B_PLANE + row * 8 + ((kb ^ ((row >> 3) & 1)) << 2) : -1;
   }
 
-  bf4 araw[6];
+  constexpr bool PF2 = (FLAGS & W43_F_PF2) != 0;
+  bf4 araw[PF2 ? 2 : 1][6];   // PF2: chunk parity -> register set
   bf4 breg[3][BLD];   // weights in flight: requested in stage s for stage s+3, written to the ring in stage s+1
   bool chunk_ok = true;
-  auto load_item = [&]() {
+  auto load_item = [&](auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     const unsigned so = (unsigned)c0 * 4u;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const bool ok = chunk_ok && ((a_ok >> j) & 1u);
-      araw[j] = conv_buf_load(arsrc, ok ? a_off + (unsigned)j * a_pix : OOB, so);
+      araw[SET][j] = conv_buf_load(arsrc, ok ? a_off + (unsigned)j * a_pix : OOB, so);
     }
   };
-  auto store_item = [&](int stage) {
+  auto store_item = [&](int stage, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     float* As = smem + stage * A_STAGE + a_lds;
     bf4 v[6];
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-      const float d0 = araw[0][c], d1 = araw[1][c], d2 = araw[2][c], d3 = araw[3][c], d4 = araw[4][c], d5 = araw[5][c];
+      const float d0 = araw[SET][0][c], d1 = araw[SET][1][c], d2 = araw[SET][2][c], d3 = araw[SET][3][c], d4 = araw[SET][4][c], d5 = araw[SET][5][c];
       const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
       const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
       v[0][c] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
@@ -189,9 +200,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
   const int b_ad = 2 * A_STAGE4 + (NU * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
   int a_cur = a_ad;
 
+  bool in_loop = false;
   bf4 fa[3][TM], fb[3][TN];   // [nu step j mod 3][tile]: triple buffered
   auto fetch = [&](auto dy_c, auto j_c, int a_base) {
     constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
+    if constexpr ((FLAGS & W43_DBG_NOFRAG) != 0) { if (in_loop) return; }
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) fa[J % 3][mt] = smem4[a_base + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
 #pragma unroll
@@ -211,25 +224,35 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
   setup_seg();
-  load_item();        // every request of the prologue first, then the stores: one load latency instead of three
+  load_item(C0{});    // every request of the prologue first, then the stores: one load latency instead of three
   load_b(0, 0);
   load_b(1, 1);
   load_b(2, 2);
-  store_item(0);
+  if constexpr (PF2) { next_chunk(1); load_item(C1{}); }   // chunk 1 stays in registers until chunk 0's dy = 1 stage
+  store_item(0, C0{});
   store_b(0, 0);
   store_b(1, 1);
-  next_chunk(1);
+  next_chunk(PF2 ? 2 : 1);
   __syncthreads();
   fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur);
   int a_stage = 0;
-  for (int kc = 0; kc < nkc; ++kc) {
+  if constexpr ((FLAGS & W43_DBG_NOFRAG) != 0) {
+    fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, a_cur);
+    fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, a_cur);
+    in_loop = true;
+  }
+  // one K chunk; PAR = parity of kc (PF2: the register set that receives chunk kc + 2 and held chunk kc)
+  auto chunk = [&](int kc, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
     const int s0 = kc * 3;
     const int a_next = a_ad + (a_stage ^ 1) * A_STAGE4;
     auto stage = [&](auto dy_c) {
       constexpr int DY = decltype(dy_c)::value;
-      load_b(s0 + DY + 3, DY);
-      if constexpr (DY == 0) load_item();
+      if constexpr ((FLAGS & W43_DBG_NOB) == 0) load_b(s0 + DY + 3, DY);
+      if constexpr (DY == 0 && (FLAGS & (W43_DBG_NOA | W43_DBG_NOALOAD)) == 0) load_item(std::integral_constant<int, PF2 ? PAR : 0>{});
       fetch(dy_c, std::integral_constant<int, 1>{}, a_cur);
       compute(std::integral_constant<int, 0>{});
       fetch(dy_c, std::integral_constant<int, 2>{}, a_cur);
@@ -245,16 +268,24 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
       fetch(std::integral_constant<int, (DY + 1) % 3>{}, std::integral_constant<int, 0>{}, DY == 2 ? a_next : a_cur);
       compute(std::integral_constant<int, NU - 1>{});
       __builtin_amdgcn_sched_barrier(0);
-      store_b((DY + 2) % 3, (DY + 2) % 3);
-      if constexpr (DY == 1) store_item(a_stage ^ 1);
-      __syncthreads();
+      if constexpr ((FLAGS & W43_DBG_NOB) == 0) store_b((DY + 2) % 3, (DY + 2) % 3);
+      if constexpr (DY == 1 && (FLAGS & (W43_DBG_NOA | W43_DBG_NOASTORE)) == 0) store_item(a_stage ^ 1, std::integral_constant<int, PF2 ? 1 - PAR : 0>{});
+      if constexpr ((FLAGS & W43_DBG_NOBAR) == 0) __syncthreads();
     };
     stage(std::integral_constant<int, 0>{});
     stage(std::integral_constant<int, 1>{});
     stage(std::integral_constant<int, 2>{});
-    next_chunk(kc + 2);
+    next_chunk(kc + (PF2 ? 3 : 2));
     a_stage ^= 1;
     a_cur = a_next;
+  };
+  if constexpr (PF2) {
+    for (int kc = 0; kc < nkc; kc += 2) {
+      chunk(kc, C0{});
+      if (kc + 1 < nkc) chunk(kc + 1, C1{});
+    }
+  } else {
+    for (int kc = 0; kc < nkc; ++kc) chunk(kc, C0{});
   }
 
   // ---- epilogue: y0 = (m0+m1+m2) + (m3+m4), y1 = (m1-m2) + 2(m3-m4) on half 0; y2 = (m1+m2) + 4(m3+m4),

@@ -84,6 +84,7 @@ struct OpDesc {
   int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
+  View img_in, img_out;   // warp: fused 3-channel image warp with the same flow (t = 0.5 stage)
   View in3, out2;   // warp: coarser flow to upsample / the upsampled flow it stores; flow heads: in2 = upsampled flow, out2 = v = out + in2
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
   float fscale = 1.f;
@@ -164,7 +165,7 @@ struct film_handle {
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
-  int opt_fuse = 3;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
+  int opt_fuse = 7;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
@@ -462,11 +463,11 @@ struct Planner {
       else if (op.split == 2) op.wino = 0;
     }
     // fp32: F(4,3) along x (conv_wino43_kernel, 2x fewer MFMAs than direct where F(2,3) has 1.5x) on the levels whose width
-    // fills its 128-pixel patches (at most 15 % of the last patch of a row empty); wino = 3.  "winograd" = 2 / 3 force
+    // fills its 64-pixel patches (the Q16 tiles; at most 15 % of the last patch of a row empty: 960 ... 60, 448, 256 ...); wino = 3.  "winograd" = 2 / 3 force
     // F(2,3) / F(4,3) onto every eligible layer (tests).
-    if (op.wino == 1 && h->opt_wino != 2 && L.w43_off >= 0 && (h->opt_wino == 3 || 128 * ((W + 127) / 128) * 100 <= 115 * W)) op.wino = 3;
+    if (op.wino == 1 && h->opt_wino != 2 && L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W)) op.wino = 3;
     if (op.split || op.wino) op.halo = 0;
-    op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_4x64_T21 : W43_4x32_T11) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
+    op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_P2) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
               : op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
@@ -709,6 +710,13 @@ struct Planner {
         View fl = view(v[l], (1 - s) * B, 0, 2);
         warp(tg + ":warp_feat" + std::to_string(s), view(feat[l], s * B, 0, fc[l]), fl,
              view(aligned[l], 0, s * fc[l], fc[l]), B, HL(l), WL(l), 0.5f);
+        if (h->opt_fuse & 4) {   // the 3-channel image rides in the same launch (extra row units)
+          OpDesc& w = P->ops.back();
+          w.tag += "+img";
+          w.img_in = view(img[l], s * B, 0, 3);
+          w.img_out = view(aligned[l], 0, 2 * fc[l] + 3 * s, 3);
+          w.bytes += 4.0 * B * HL(l) * WL(l) * 6.0;
+        } else
         warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
              view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f, false);
       }
@@ -757,8 +765,10 @@ struct Planner {
     if (op.kind == OP_CONV) for (int i = 0; i < op.nseg; ++i) rd.push_back(access(op.seg[i].v));
     else { if (op.in.buf >= 0) rd.push_back(access(op.in)); if (op.in2.buf >= 0) rd.push_back(access(op.in2)); }
     if (op.in3.buf >= 0) rd.push_back(access(op.in3));
+    if (op.img_in.buf >= 0) rd.push_back(access(op.img_in));
     if (op.out.buf >= 0) wr.push_back(access(op.out));
     if (op.out2.buf >= 0) wr.push_back(access(op.out2));
+    if (op.img_out.buf >= 0) wr.push_back(access(op.img_out));
   }
   // For every op: the LAST op of the other lane it conflicts with (RAW, WAR or WAW on overlapping channels of a
   // buffer).  Waiting for the last one is enough: a lane executes in program order.
@@ -854,6 +864,10 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.dst = mptr(arena, op.out); p.dstride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W;
       if (op.in3.buf >= 0) { p.coarse = cptr(arena, op.in3); p.flow_out = mptr(arena, op.out2); }
+      if (op.img_in.buf >= 0) {
+        p.src3 = cptr(arena, op.img_in); p.s3stride = op.img_in.stride;
+        p.dst3 = mptr(arena, op.img_out); p.d3stride = op.img_out.stride;
+      }
       return film_launch_warp(p, s);
     }
     case OP_PACK_FLOW: {
@@ -900,8 +914,11 @@ std::vector<int> wino_candidates(int Cout) {
 }
 
 std::vector<int> wino43_candidates(int Cout) {
-  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_4x64_T12, W43_4x32_T11, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11, W43_Q16_4x64_N1}
-                                            : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11};
+  // the 64-pixel ("Q16", two workgroups per CU) tiles won every layer of the 1080p plan against the 128-pixel ones
+  // (profiles/r02_conv_bench_w43.log); one 128-pixel tile stays in the list for shapes nobody measured
+  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11, W43_Q16_4x64_N1,
+                                                              W43_Q16_4x64_T21_P2, W43_Q16_4x64_T12_P2, W43_Q16_4x32_T11_P2, W43_Q16_4x64_N1_P2}
+                                            : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11, W43_Q16_4x32_T11_P2};
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD); }
   return out;
@@ -1108,6 +1125,8 @@ std::string plan_json(film_t* h, const Plan& P) {
     json_view(o, "in2", op.in2, P); o << ",";
     json_view(o, "in3", op.in3, P); o << ",";
     json_view(o, "out2", op.out2, P); o << ",";
+    json_view(o, "img_in", op.img_in, P); o << ",";
+    json_view(o, "img_out", op.img_out, P); o << ",";
     json_view(o, "out", op.out, P);
     o << ",\"segs\":[";
     for (int k = 0; k < op.nseg; ++k) {
@@ -1450,12 +1469,12 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "fuse")) {
-    if ((int)(value & 3) != h->opt_fuse) {  // plans carry the op list: drop them
+    if ((int)(value & 7) != h->opt_fuse) {  // plans carry the op list: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
       h->plans.clear();
       h->last_plan = nullptr;
-      h->opt_fuse = (int)(value & 3);
+      h->opt_fuse = (int)(value & 7);
     }
   }
   else if (!strcmp(key, "fold2x2")) {

@@ -130,6 +130,13 @@ struct WarpParams {
   // and it is written to flow_out [NB][H][W][2] (C % 4 == 0 launches only) - the former flow_up launch.
   const float* coarse;
   float* flow_out;
+  // Fused 3-channel image warp of the t = 0.5 stage (interpolator.py:167-178 warps [image | features] as one tensor): the
+  // same flow also samples src3 [NB][H][W][3] (pixel stride s3stride) into dst3 (pixel stride d3stride); W extra units
+  // per row behind the feature units of a row band do it - the former warp_c3 launch.  nullptr: none.
+  const float* src3;
+  int s3stride;
+  float* dst3;
+  int d3stride;
 };
 
 // Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:
@@ -176,7 +183,9 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
 // 0-2: 128-pixel patches, 8 waves, one workgroup per CU; 3-5 ("Q16"): 64-pixel patches (an MFMA row tile = two patch rows x 16
 // quads), 4 waves, 72 / 54 KB of LDS -> two workgroups per CU.  Same k-ordered sums: the autotuner picks freely among them.
 enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_4x64_T21 = 3, W43_Q16_4x64_T12 = 4, W43_Q16_4x32_T11 = 5,
-                  W43_Q16_4x64_N1 = 6 /* a wave owns all six nu planes of one 32x32 tile: no epilogue exchange */ };
+                  W43_Q16_4x64_N1 = 6 /* a wave owns all six nu planes of one 32x32 tile: no epilogue exchange */,
+                  /* the Q16 tiles with the activation loads requested two K chunks ahead (second register set) */
+                  W43_Q16_4x64_T21_P2 = 7, W43_Q16_4x64_T12_P2 = 8, W43_Q16_4x32_T11_P2 = 9, W43_Q16_4x64_N1_P2 = 10 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

@@ -251,11 +251,33 @@ constexpr int WARP_ROWS = 8;
 __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int G = p.C >> 2;
   const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  if (i >= (unsigned)(p.W * G)) return;
-  int x, g;
-  split_unit(i, G, x, g);
+  const unsigned nfeat = (unsigned)(p.W * G);
   const int yb = blockIdx.y * WARP_ROWS;
   const int64_t b = blockIdx.z;
+  if (i >= nfeat) {
+    // image units of the band (behind its feature units; only the last workgroups have any): one thread = one pixel
+    // of one row of the band, 3 channels
+    if (p.src3 == nullptr || i - nfeat >= (unsigned)(p.W * WARP_ROWS)) return;
+    int k, x;
+    split_unit(i - nfeat, p.W, k, x);
+    const int y = yb + k;
+    if (y >= p.H) return;
+    const float2 fl = warp_flow_at(p, b, y, x);
+    const float qy = (float)y + p.fscale * fl.y;
+    const float qx = (float)x + p.fscale * fl.x;
+    int fy, fx;
+    float ay, ax;
+    warp_axis(qy, p.H, fy, ay);
+    warp_axis(qx, p.W, fx, ax);
+    const float* s00 = p.src3 + ((b * p.H + fy) * p.W + fx) * p.s3stride;
+    const float* s10 = s00 + (int64_t)p.W * p.s3stride;
+    float* d = p.dst3 + ((b * p.H + y) * p.W + x) * p.d3stride;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[c] = lerp3(s00[c], s00[p.s3stride + c], s10[c], s10[p.s3stride + c], ax, ay);
+    return;
+  }
+  int x, g;
+  split_unit(i, G, x, g);
   const int64_t rowpitch = (int64_t)p.W * p.sstride;
   const float* const img = p.src + b * p.H * rowpitch + g * 4;
 #pragma unroll
@@ -391,10 +413,11 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
   if (units >= (1 << 24) || p.H > 65535 || p.NB > 65535) return hipErrorInvalidValue;
   if (p.coarse != nullptr && ((p.H | p.W) & 1)) return hipErrorInvalidValue;
   if (p.C == 3) {
-    if (p.flow_out != nullptr) return hipErrorInvalidValue;
+    if (p.flow_out != nullptr || p.src3 != nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(warp_c3_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB), dim3(256), 0, s, p);
   } else {
-    hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB),
+    const int64_t all = units + (p.src3 != nullptr ? (int64_t)p.W * WARP_ROWS : 0);
+    hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)((all + 255) / 256), (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB),
                        dim3(256), 0, s, p);
   }
   return hipGetLastError();

@@ -138,9 +138,10 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  (2-16 partial sums over K ranges, added in split order by a second kernel: deterministic, and the
  *                  factor depends on the level size and the layer only, never on the batch); it is what bounds the
  *                  latency of small frames.  Changing it drops the cached plans.
- *   "fuse"    0/1  1 (default): tf.image.resize(2 * v) of the flow estimator is computed inside the warp kernels that consume
- *                  it and v = residual + upsampled flow inside the flow-head kernels (identical arithmetic, bit-identical
- *                  results, 12 launches fewer per forward).  0: separate flow_up / flow_add launches.  Drops the cached plans.
+ *   "fuse"    bits 7 (default): small-launch fusion, identical arithmetic and bit-identical results.  1: tf.image.resize(2 * v)
+ *                  of the flow estimator inside the warp kernels that consume it; 2: v = residual + upsampled flow inside
+ *                  the flow-head kernels; 4: the 3-channel image warps of the t = 0.5 stage inside the feature warps of the
+ *                  same flow (22 launches fewer per forward in all).  0: one launch per reference op.  Drops the cached plans.
  *   "fold2x2" 0/1  1 (default): the decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) runs as four
  *                  sub-pixel phase convolutions on the low-resolution input with pre-summed weights (9 taps per 4
  *                  outputs instead of 16; an exact regrouping of the sum, rounding differs at the 1e-7 level).

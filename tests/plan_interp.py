@@ -183,6 +183,9 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             else:
                 flow = np.ascontiguousarray(_view(arena, op['in2'], nb, h, w))
             _view(arena, op['out'], nb, h, w)[...] = fo.warp(src, np.float32(op['fscale']) * flow)
+            if op.get('img_in', {}).get('buf'):     # fused 3-channel image warp with the same flow
+                im = np.ascontiguousarray(_view(arena, op['img_in'], nb, h, w))
+                _view(arena, op['img_out'], nb, h, w)[...] = fo.warp(im, np.float32(op['fscale']) * flow)
         elif k == 'pack_flow':
             m = op['n']
             bf = _view(arena, op['in'], 1, 1, m)

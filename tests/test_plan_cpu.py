@@ -263,8 +263,8 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
 
         def rw(op):
             rd = [acc(sg['v']) for sg in op.get('segs', [])] if op['kind'] == 'conv_mfma' else [acc(op.get('in')), acc(op.get('in2'))]
-            rd.append(acc(op.get('in3')))
-            return [a for a in rd if a], [a for a in [acc(op.get('out')), acc(op.get('out2'))] if a]
+            rd += [acc(op.get('in3')), acc(op.get('img_in'))]
+            return [a for a in rd if a], [a for a in [acc(op.get('out')), acc(op.get('out2')), acc(op.get('img_out'))] if a]
 
         def hit(a, b):
             return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
