@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -155,7 +157,9 @@ struct film_handle {
   std::map<std::string, HostTensor> host_w;
   std::vector<LayerPack> layers;
   std::map<std::string, int> layer_idx;
-  int64_t packed_floats = 0;
+  int64_t packed_floats = 0;          // floats of the PACKED PREFIX (groups [0, groups_packed)); group_end[3] = all layouts
+  int64_t group_end[4] = {0, 0, 0, 0};  // end offset of layout group g (see film_create): 0 base, 1 F(2,3), 2 halo, 3 bf16 splits
+  int groups_packed = 0;
   std::vector<float> packed_host;
   float* packed_dev = nullptr;
   bool finalized = false;
@@ -176,6 +180,8 @@ struct film_handle {
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
 };
+
+extern "C" int film_ensure_groups_(film_t* h, int n);   // packs + uploads weight layout groups [groups_packed, n) on demand (internal)
 
 namespace {
 
@@ -310,32 +316,38 @@ void build_layers(film_t* h) {
     add("fusion/convs_" + std::to_string(i) + "_2", 3, 3, ff[i], ff[i], identity_perm(ff[i]));
   }
   add("fusion/output_conv", 1, 1, ff[0], 3, identity_perm(ff[0]));
+  // Weight layouts in four contiguous GROUPS, packed on demand (film_finalize packs group 0; the planner asks for the
+  // others when a plan first needs them) so that the default fp32 path neither builds nor broadcasts the copies it never
+  // reads:  0 = what the default plan runs on: K-major / first-layer / 1x1 layouts + biases, the phase-summed 2x2
+  //             layers, the F(4,3) copy                                                     (3.1x the parameters)
+  //         1 = F(2,3) copy (conv_wino_kernel: levels narrower than the F(4,3) patches)
+  //         2 = halo copy (conv_halo_kernel: option winograd = 0 / halo_all)
+  //         3 = bf16 split copies (precision modes bf16x6 / bf16x3)
   int64_t off = 0;
+  auto al = [&]() { off = (off + 3) & ~int64_t(3); };
   for (auto& L : h->layers) {
-    L.w_off = off;
-    off += L.packed_rows() * L.cout;
-    off = (off + 3) & ~int64_t(3);
-    L.b_off = off;
-    off += L.cout;
-    off = (off + 3) & ~int64_t(3);
-    if (L.has_fold()) {
-      L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; off = (off + 3) & ~int64_t(3);
-      L.wfx_off = off; off += (int64_t)9 * L.ctot() * L.cout; off = (off + 3) & ~int64_t(3);
-    }
-    if (L.has_halo()) {
-      L.wh_off = off; off += L.packed_rows() * L.cout;
-      off = (off + 3) & ~int64_t(3);
-      L.ws_off = off; off += (L.packed_rows() * L.cout * 3 + 1) / 2;
-      off = (off + 3) & ~int64_t(3);
-      L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12;
-      off = (off + 3) & ~int64_t(3);
-      L.wx_off = off; off += L.packed_rows() * L.cout / 9 * 12;
-      off = (off + 3) & ~int64_t(3);
-      L.w43_off = off; off += L.packed_rows() * L.cout / 9 * 18;
-    }
-    off = (off + 3) & ~int64_t(3);
+    L.w_off = off; off += L.packed_rows() * L.cout; al();
+    L.b_off = off; off += L.cout; al();
+    if (L.has_fold()) { L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; al(); }
+    if (L.has_halo()) { L.w43_off = off; off += L.packed_rows() * L.cout / 9 * 18; al(); }
   }
-  h->packed_floats = off;
+  h->group_end[0] = off;
+  for (auto& L : h->layers)
+    if (L.has_halo()) { L.ww_off = off; off += L.packed_rows() * L.cout / 9 * 12; al(); }
+  h->group_end[1] = off;
+  for (auto& L : h->layers)
+    if (L.has_halo()) { L.wh_off = off; off += L.packed_rows() * L.cout; al(); }
+  h->group_end[2] = off;
+  for (auto& L : h->layers) {
+    if (L.has_fold()) { L.wfx_off = off; off += (int64_t)9 * L.ctot() * L.cout; al(); }
+    if (L.has_halo()) {
+      L.ws_off = off; off += (L.packed_rows() * L.cout * 3 + 1) / 2; al();
+      L.wx_off = off; off += L.packed_rows() * L.cout / 9 * 12; al();
+    }
+  }
+  h->group_end[3] = off;
+  h->packed_floats = 0;
+  h->groups_packed = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,6 +403,12 @@ struct Planner {
     return (Cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_HALO | CONV_TILE_XCD;
   }
 
+  // the weight layout group a kernel family reads must be packed (and on the device) before the plan can run
+  void need_groups(int n) {
+    if (!h->finalized || n <= h->groups_packed) return;
+    if (film_ensure_groups_(h, n) != FILM_OK) { bad = true; bad_msg = h->err; }
+  }
+
   void conv(const std::string& tag, const std::string& layer, std::vector<SegDesc> segs, View out, int NB, int H,
             int W, bool leaky) {
     const LayerPack& L = h->layers[h->layer_idx.at(layer)];
@@ -426,6 +444,7 @@ struct Planner {
       if (h->opt_precision == 2 && L.wfx_off >= 0 && L.cout % 64 == 0 && ((int64_t)f.H * f.W >= 2048 || h->opt_halo_all)) {
         f.split = 2;   // precision mode bf16x3: one halo-staged patch, nine (tap, phase) steps (conv_foldx3_kernel)
         f.tile = FX3_4x64 | CONV_TILE_FOLDX3 | CONV_TILE_XCD;
+        need_groups(4);
       }
       f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin;   // algorithmic FLOPs of the reference op
       f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout);
@@ -467,6 +486,7 @@ struct Planner {
     // F(2,3) / F(4,3) onto every eligible layer (tests).
     if (op.wino == 1 && h->opt_wino != 2 && L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W)) op.wino = 3;
     if (op.split || op.wino) op.halo = 0;
+    need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
     op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_P2) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
               : op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
@@ -1269,186 +1289,285 @@ int film_set_weight(film_t* h, const char* name, const float* data, const int64_
   return FILM_OK;
 }
 
-static int upload_packed(film_t* h) {
-  if (h->plan_only) return FILM_OK;
+// Uploads the floats [from, to) of the packed blob.  The device buffer is sized for every layout group once (1.1 GB of
+// 288): groups packed later land at their fixed offsets and no plan has to be rebuilt.
+static int upload_packed(film_t* h, int64_t from, int64_t to) {
+  if (h->plan_only || to <= from) return FILM_OK;
   HIPCHK(h, hipSetDevice(h->device));
-  if (!h->packed_dev) HIPCHK(h, hipMalloc(&h->packed_dev, (size_t)h->packed_floats * sizeof(float)));
-  HIPCHK(h, hipMemcpy(h->packed_dev, h->packed_host.data(), (size_t)h->packed_floats * sizeof(float), hipMemcpyHostToDevice));
+  if (!h->packed_dev) HIPCHK(h, hipMalloc(&h->packed_dev, (size_t)h->group_end[3] * sizeof(float)));
+  HIPCHK(h, hipMemcpy(h->packed_dev + from, h->packed_host.data() + from, (size_t)(to - from) * sizeof(float), hipMemcpyHostToDevice));
   return FILM_OK;
 }
 
-int film_finalize(film_t* h) {
-  if (!h) return FILM_ERR_INVALID;
-  h->packed_host.assign((size_t)h->packed_floats, 0.f);
-  for (const LayerPack& L : h->layers) {
-    auto kw = h->host_w.find(L.name + "/kernel"), bw = h->host_w.find(L.name + "/bias");
-    if (kw == h->host_w.end() || bw == h->host_w.end()) return fail(h, FILM_ERR_STATE, "missing weight '%s'", L.name.c_str());
-    const float* src = kw->second.data.data();
-    float* dst = h->packed_host.data() + L.w_off;
-    const int ct = L.ctot();
+// Packs the layouts of `group` of layer L for the output channels [co0, co1) (the unit of work of the packing threads;
+// every output channel owns disjoint ranges of every layout).  Layers without a per-channel layout (first layer, 1x1
+// heads) and the biases are handled by the caller of co0 == 0.
+static void pack_layer_group(film_t* h, const LayerPack& L, int group, int co0, int co1) {
+  const float* src = h->host_w.at(L.name + "/kernel").data.data();
+  float* const base = h->packed_host.data();
+  const int ct = L.ctot();
+  if (group == 0 && co0 == 0) {
+    memcpy(base + L.b_off, h->host_w.at(L.name + "/bias").data.data(), sizeof(float) * L.cout);
+    float* dst = base + L.w_off;
     if (L.c3) {
       for (int tap = 0; tap < 9; ++tap)
         for (int c = 0; c < 3; ++c)
           memcpy(dst + ((size_t)tap * 4 + c) * L.cout, src + ((size_t)tap * 3 + c) * L.cout, sizeof(float) * L.cout);
-    } else if (L.kmajor()) {
-      // One pass per (tap, 16-channel chunk): the 16 source rows (each `cout` contiguous floats) stay in L1 while
-      // every output channel receives its 16 contiguous k values - in the K-major copy, in the halo copy and (3x3
-      // layers) as three bf16 planes.  (A channel-outer loop with one strided store per weight took 17 s here.)
-      const int ntap = L.kh * L.kw;
-      const size_t ktot = (size_t)ntap * ct;
-      const size_t nkc = (size_t)ct / 16;
-      float* dh = L.wh_off >= 0 ? h->packed_host.data() + L.wh_off : nullptr;
-      uint16_t* ds = L.ws_off >= 0 ? reinterpret_cast<uint16_t*>(h->packed_host.data() + L.ws_off) : nullptr;
-      for (int tap = 0; tap < ntap; ++tap)
-        for (size_t kc = 0; kc < nkc; ++kc) {
-          const float* rows[16];
-          for (int j = 0; j < 16; ++j) {
-            const int ref = L.perm[kc * 16 + j];
-            rows[j] = ref < 0 ? nullptr : src + ((size_t)tap * L.cin + ref) * L.cout;  // nullptr: zero (padding) channel
-          }
-          for (int co = 0; co < L.cout; ++co) {
-            float v[16];
-            for (int j = 0; j < 16; ++j) v[j] = rows[j] ? rows[j][co] : 0.f;
-            memcpy(dst + (size_t)co * ktot + (size_t)tap * ct + kc * 16, v, sizeof(v));
-            if (dh) memcpy(dh + (((size_t)co * nkc + kc) * 9 + tap) * 16, v, sizeof(v));
-            if (ds) {  // exact 3-way bf16 split, round-to-nearest-even pieces (same as conv_split4 on the device)
-              uint16_t* d = ds + (((size_t)co * nkc + kc) * 9 + tap) * 48;
-              for (int j = 0; j < 16; ++j) {
-                const uint16_t hb = bf16_rne(v[j]);
-                const float r = v[j] - bf16_to_float(hb);
-                const uint16_t mb = bf16_rne(r);
-                const float q = r - bf16_to_float(mb);
-                d[j] = hb; d[16 + j] = mb; d[32 + j] = bf16_rne(q);
-              }
+    } else if (!L.kmajor()) {
+      for (int tap = 0; tap < L.kh * L.kw; ++tap)
+        for (int ci = 0; ci < ct; ++ci) {
+          const int ref = L.perm[ci];
+          if (ref < 0) continue;  // zero row (padding channel)
+          memcpy(dst + ((size_t)tap * ct + ci) * L.cout, src + ((size_t)tap * L.cin + ref) * L.cout, sizeof(float) * L.cout);
+        }
+    }
+  }
+  if (!L.kmajor()) return;
+  const int ntap = L.kh * L.kw;
+  const size_t ktot = (size_t)ntap * ct;
+  const size_t nkc = (size_t)ct / 16;
+  // ---- K-major copy (group 0), halo copy (group 2), bf16x6 planes (group 3): one pass per (tap, 16-channel chunk); the
+  // 16 source rows (each `cout` contiguous floats) stay in L1 while every output channel receives its 16 k values
+  float* dk = group == 0 ? base + L.w_off : nullptr;
+  float* dh = group == 2 && L.wh_off >= 0 ? base + L.wh_off : nullptr;
+  uint16_t* ds = group == 3 && L.ws_off >= 0 ? reinterpret_cast<uint16_t*>(base + L.ws_off) : nullptr;
+  if (dk || dh || ds)
+    for (int tap = 0; tap < ntap; ++tap)
+      for (size_t kc = 0; kc < nkc; ++kc) {
+        const float* rows[16];
+        for (int j = 0; j < 16; ++j) {
+          const int ref = L.perm[kc * 16 + j];
+          rows[j] = ref < 0 ? nullptr : src + ((size_t)tap * L.cin + ref) * L.cout;  // nullptr: zero (padding) channel
+        }
+        for (int co = co0; co < co1; ++co) {
+          float v[16];
+          for (int j = 0; j < 16; ++j) v[j] = rows[j] ? rows[j][co] : 0.f;
+          if (dk) memcpy(dk + (size_t)co * ktot + (size_t)tap * ct + kc * 16, v, sizeof(v));
+          if (dh) memcpy(dh + (((size_t)co * nkc + kc) * 9 + tap) * 16, v, sizeof(v));
+          if (ds) {  // exact 3-way bf16 split, round-to-nearest-even pieces (same as conv_split4 on the device)
+            uint16_t* d = ds + (((size_t)co * nkc + kc) * 9 + tap) * 48;
+            for (int j = 0; j < 16; ++j) {
+              const uint16_t hb = bf16_rne(v[j]);
+              const float r = v[j] - bf16_to_float(hb);
+              const uint16_t mb = bf16_rne(r);
+              const float q = r - bf16_to_float(mb);
+              d[j] = hb; d[16 + j] = mb; d[32 + j] = bf16_rne(q);
             }
           }
         }
-      if (L.wf_off >= 0) {  // sub-pixel phases of upsample + 2x2: weights of the taps that read the same input pixel, summed
-        float* df = h->packed_host.data() + L.wf_off;
-        uint16_t* dfx = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.wfx_off);
-        const size_t nk16f = (size_t)ct / 16;
-        // step of (tap a*2+b, phase py*2+px) in conv_foldx3_kernel's order (taps 00 00 00 | 00 01 01 | 10 10 11)
-        static const int kFoldStep[4][4] = {{0, 1, 2, 3}, {-1, 4, -1, 5}, {-1, -1, 6, 7}, {-1, -1, -1, 8}};
-        for (int py = 0; py < 2; ++py)
-          for (int px = 0; px < 2; ++px) {
-            const int nt = (py + 1) * (px + 1);
-            const size_t kph = (size_t)nt * ct;
-            int t = 0;
-            for (int a = 0; a <= py; ++a)
-              for (int b = 0; b <= px; ++b, ++t)
-                for (int ci = 0; ci < ct; ++ci) {
-                  const int ref = L.perm[ci];
-                  if (ref < 0) continue;
-                  for (int co = 0; co < L.cout; ++co) {
-                    float acc = 0.f;  // kernel taps (dy, dx) with (py & dy) == a and (px & dx) == b, in raster order
-                    for (int dy = 0; dy < 2; ++dy)
-                      for (int dx = 0; dx < 2; ++dx)
-                        if ((py & dy) == a && (px & dx) == b) acc += src[((size_t)(dy * 2 + dx) * L.cin + ref) * L.cout + co];
-                    df[(size_t)co * kph + (size_t)t * ct + ci] = acc;
-                    const int step = kFoldStep[a * 2 + b][py * 2 + px];
-                    uint16_t* d = dfx + (((size_t)co * nk16f + ci / 16) * 9 + step) * 32 + ci % 16;
-                    const uint16_t hb = bf16_rne(acc);
-                    d[0] = hb;
-                    d[16] = bf16_rne(acc - bf16_to_float(hb));
-                  }
-                }
-            df += kph * L.cout;
-          }
       }
-      if (L.ww_off >= 0) {  // F(2,3) along x: u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2 per (dy, cin, cout);
-                            // 8-channel chunks: [Cout][chunk8][nu*3+dy][8]
-        float* dw = h->packed_host.data() + L.ww_off;
-        uint16_t* dx3 = reinterpret_cast<uint16_t*>(h->packed_host.data() + L.wx_off);
-        float* d43 = h->packed_host.data() + L.w43_off;
-        const size_t nk8 = (size_t)ct / 8, nk16 = (size_t)ct / 16;
-        for (int dy = 0; dy < 3; ++dy)
-          for (size_t kc = 0; kc < nk8; ++kc) {
-            const float* rows[3][8];
-            for (int dx = 0; dx < 3; ++dx)
-              for (int j = 0; j < 8; ++j) {
-                const int ref = L.perm[kc * 8 + j];
-                rows[dx][j] = ref < 0 ? nullptr : src + ((size_t)(dy * 3 + dx) * L.cin + ref) * L.cout;
-              }
-            for (int co = 0; co < L.cout; ++co) {
-              float u[4][8];
-              for (int j = 0; j < 8; ++j) {
-                const float g0 = rows[0][j] ? rows[0][j][co] : 0.f, g1 = rows[1][j] ? rows[1][j][co] : 0.f,
-                            g2 = rows[2][j] ? rows[2][j][co] : 0.f;
-                u[0][j] = g0; u[1][j] = ((g0 + g2) + g1) * 0.5f; u[2][j] = ((g0 + g2) - g1) * 0.5f; u[3][j] = g2;
-              }
-              {  // F(4,3) along x (conv_wino43_impl.h): [Cout][chunk8][dy][nu 6][8]
-                float* d = d43 + ((((size_t)co * nk8 + kc) * 3 + dy) * 6) * 8;
-                for (int j = 0; j < 8; ++j) {
-                  const float g0 = rows[0][j] ? rows[0][j][co] : 0.f, g1 = rows[1][j] ? rows[1][j][co] : 0.f,
-                              g2 = rows[2][j] ? rows[2][j][co] : 0.f;
-                  const float e = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), o = g1 * (1.f / 12.f);
-                  d[0 * 8 + j] = g0 * 0.25f;
-                  d[1 * 8 + j] = -((g0 + g2) + g1) * (1.f / 6.f);
-                  d[2 * 8 + j] = -((g0 + g2) - g1) * (1.f / 6.f);
-                  d[3 * 8 + j] = e + o;
-                  d[4 * 8 + j] = e - o;
-                  d[5 * 8 + j] = g2;
-                }
-              }
-              for (int nu = 0; nu < 4; ++nu) {
-                memcpy(dw + (((size_t)co * nk8 + kc) * 12 + nu * 3 + dy) * 8, u[nu], sizeof(u[nu]));
-                // the same transformed weights as nearest bf16 hi / mid planes (nu = 2h + j)
-                uint16_t* d = dx3 + ((((size_t)co * nk16 + kc / 2) * 3 + dy) * 2 + (nu & 1)) * 64 + (nu >> 1) * 32 + (kc & 1) * 8;
-                for (int j = 0; j < 8; ++j) {
-                  const uint16_t hb = bf16_rne(u[nu][j]);
-                  d[j] = hb;
-                  d[16 + j] = bf16_rne(u[nu][j] - bf16_to_float(hb));
+  // ---- sub-pixel phases of upsample + 2x2: weights of the taps that read the same input pixel, summed (fp32: group 0;
+  // bf16 hi / mid for conv_foldx3_kernel: group 3)
+  if (L.wf_off >= 0 && (group == 0 || group == 3)) {
+    float* df = base + L.wf_off;
+    uint16_t* dfx = reinterpret_cast<uint16_t*>(base + L.wfx_off);
+    const size_t nk16f = (size_t)ct / 16;
+    // step of (tap a*2+b, phase py*2+px) in conv_foldx3_kernel's order (taps 00 00 00 | 00 01 01 | 10 10 11)
+    static const int kFoldStep[4][4] = {{0, 1, 2, 3}, {-1, 4, -1, 5}, {-1, -1, 6, 7}, {-1, -1, -1, 8}};
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px) {
+        const int nt = (py + 1) * (px + 1);
+        const size_t kph = (size_t)nt * ct;
+        int t = 0;
+        for (int a = 0; a <= py; ++a)
+          for (int b = 0; b <= px; ++b, ++t)
+            for (int ci = 0; ci < ct; ++ci) {
+              const int ref = L.perm[ci];
+              if (ref < 0) continue;
+              for (int co = co0; co < co1; ++co) {
+                float acc = 0.f;  // kernel taps (dy, dx) with (py & dy) == a and (px & dx) == b, in raster order
+                for (int dy = 0; dy < 2; ++dy)
+                  for (int dx = 0; dx < 2; ++dx)
+                    if ((py & dy) == a && (px & dx) == b) acc += src[((size_t)(dy * 2 + dx) * L.cin + ref) * L.cout + co];
+                if (group == 0) df[(size_t)co * kph + (size_t)t * ct + ci] = acc;
+                else {
+                  const int step = kFoldStep[a * 2 + b][py * 2 + px];
+                  uint16_t* d = dfx + (((size_t)co * nk16f + ci / 16) * 9 + step) * 32 + ci % 16;
+                  const uint16_t hb = bf16_rne(acc);
+                  d[0] = hb;
+                  d[16] = bf16_rne(acc - bf16_to_float(hb));
                 }
               }
             }
-          }
+        df += kph * L.cout;
       }
-    } else
-    for (int tap = 0; tap < L.kh * L.kw; ++tap)
-      for (int ci = 0; ci < ct; ++ci) {
-        const int ref = L.perm[ci];
-        if (ref < 0) continue;  // zero row (padding channel)
-        memcpy(dst + ((size_t)tap * ct + ci) * L.cout, src + ((size_t)tap * L.cin + ref) * L.cout, sizeof(float) * L.cout);
-      }
-    memcpy(h->packed_host.data() + L.b_off, bw->second.data.data(), sizeof(float) * L.cout);
   }
-  int rc = upload_packed(h);
+  // ---- Winograd copies along x: F(4,3) [Cout][chunk8][dy][nu 6][8] (group 0), F(2,3) [Cout][chunk8][nu*3+dy][8]
+  // (u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2; group 1) and its bf16 hi / mid planes (group 3)
+  if (L.ww_off >= 0 && (group == 0 || group == 1 || group == 3)) {
+    float* dw = base + L.ww_off;
+    uint16_t* dx3 = reinterpret_cast<uint16_t*>(base + L.wx_off);
+    float* d43 = base + L.w43_off;
+    const size_t nk8 = (size_t)ct / 8, nk16 = (size_t)ct / 16;
+    for (int dy = 0; dy < 3; ++dy)
+      for (size_t kc = 0; kc < nk8; ++kc) {
+        const float* rows[3][8];
+        for (int dx = 0; dx < 3; ++dx)
+          for (int j = 0; j < 8; ++j) {
+            const int ref = L.perm[kc * 8 + j];
+            rows[dx][j] = ref < 0 ? nullptr : src + ((size_t)(dy * 3 + dx) * L.cin + ref) * L.cout;
+          }
+        for (int co = co0; co < co1; ++co) {
+          float g[3][8];
+          for (int dx = 0; dx < 3; ++dx)
+            for (int j = 0; j < 8; ++j) g[dx][j] = rows[dx][j] ? rows[dx][j][co] : 0.f;
+          if (group == 0) {
+            float* d = d43 + ((((size_t)co * nk8 + kc) * 3 + dy) * 6) * 8;
+            for (int j = 0; j < 8; ++j) {
+              const float g0 = g[0][j], g1 = g[1][j], g2 = g[2][j];
+              const float e = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), o = g1 * (1.f / 12.f);
+              d[0 * 8 + j] = g0 * 0.25f;
+              d[1 * 8 + j] = -((g0 + g2) + g1) * (1.f / 6.f);
+              d[2 * 8 + j] = -((g0 + g2) - g1) * (1.f / 6.f);
+              d[3 * 8 + j] = e + o;
+              d[4 * 8 + j] = e - o;
+              d[5 * 8 + j] = g2;
+            }
+            continue;
+          }
+          float u[4][8];
+          for (int j = 0; j < 8; ++j) {
+            const float g0 = g[0][j], g1 = g[1][j], g2 = g[2][j];
+            u[0][j] = g0; u[1][j] = ((g0 + g2) + g1) * 0.5f; u[2][j] = ((g0 + g2) - g1) * 0.5f; u[3][j] = g2;
+          }
+          for (int nu = 0; nu < 4; ++nu) {
+            if (group == 1) { memcpy(dw + (((size_t)co * nk8 + kc) * 12 + nu * 3 + dy) * 8, u[nu], sizeof(u[nu])); continue; }
+            // the same transformed weights as nearest bf16 hi / mid planes (nu = 2h + j)
+            uint16_t* d = dx3 + ((((size_t)co * nk16 + kc / 2) * 3 + dy) * 2 + (nu & 1)) * 64 + (nu >> 1) * 32 + (kc & 1) * 8;
+            for (int j = 0; j < 8; ++j) {
+              const uint16_t hb = bf16_rne(u[nu][j]);
+              d[j] = hb;
+              d[16 + j] = bf16_rne(u[nu][j] - bf16_to_float(hb));
+            }
+          }
+        }
+      }
+  }
+}
+
+// Packs layout groups [h->groups_packed, n) from the HWIO tensors (kept on the host) and uploads them.  Work items =
+// (layer, 32 output channels), pulled from an atomic counter by up to 32 threads: 137.7 MB of parameters into the
+// default group 0 in well under a second on the hosts this runs on (it took 7 s single-threaded for every layout).
+int film_ensure_groups_(film_t* h, int n) {
+  if (n <= h->groups_packed) return FILM_OK;
+  if (n > 4) n = 4;
+  for (const LayerPack& L : h->layers)
+    if (!h->host_w.count(L.name + "/kernel") || !h->host_w.count(L.name + "/bias")) return fail(h, FILM_ERR_STATE, "missing weight '%s'", L.name.c_str());
+  const int64_t from = h->groups_packed ? h->group_end[h->groups_packed - 1] : 0, to = h->group_end[n - 1];
+  h->packed_host.resize((size_t)to, 0.f);
+  struct Item { const LayerPack* L; int co0, co1; };
+  std::vector<Item> items;
+  for (const LayerPack& L : h->layers)
+    for (int co = 0; co < L.cout; co += 32) items.push_back({&L, co, std::min(L.cout, co + 32)});
+  for (int g = h->groups_packed; g < n; ++g) {
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+      for (size_t i; (i = next.fetch_add(1)) < items.size();) pack_layer_group(h, *items[i].L, g, items[i].co0, items[i].co1);
+    };
+    const unsigned nth = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < nth; ++t) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+  }
+  h->groups_packed = n;
+  h->packed_floats = to;
+  return upload_packed(h, from, to);
+}
+
+// layout groups the current options need at once (the planner asks for more when a plan needs them)
+static int groups_for_options(const film_t* h) {
+  int n = 1;
+  if (h->opt_wino == 2) n = std::max(n, 2);
+  if (h->opt_wino == 0 || h->opt_halo_all) n = std::max(n, 3);
+  if (h->opt_precision) n = 4;
+  return n;
+}
+
+int film_finalize(film_t* h) {
+  if (!h) return FILM_ERR_INVALID;
+  h->groups_packed = 0;
+  h->packed_floats = 0;
+  h->packed_host.clear();
+  h->finalized = false;
+  int rc = film_ensure_groups_(h, groups_for_options(h));
   if (rc) return rc;
   h->finalized = true;
   return FILM_OK;
 }
 
+// ---- the parameter set as ONE flat blob (what ranks exchange): per layer, in layer order, the HWIO kernel then the bias ----
+static int64_t flat_floats(const film_t* h) {
+  int64_t n = 0;
+  for (const LayerPack& L : h->layers) n += (int64_t)L.kh * L.kw * L.cin * L.cout + L.cout;
+  return n;
+}
+
 int film_packed_size(film_t* h, int64_t* n) {
   if (!h || !n) return FILM_ERR_INVALID;
-  *n = h->packed_floats;
+  *n = flat_floats(h);
   return FILM_OK;
 }
 
 int film_export_packed(film_t* h, float* dst, int64_t cap, int mem_kind) {
   if (!h || !dst) return FILM_ERR_INVALID;
   if (!h->finalized) return fail(h, FILM_ERR_STATE, "film_finalize has not been called");
-  if (cap < h->packed_floats) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)h->packed_floats);
-  if (mem_kind == FILM_MEM_HOST) { memcpy(dst, h->packed_host.data(), (size_t)h->packed_floats * sizeof(float)); return FILM_OK; }
-  if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle has no device");
-  HIPCHK(h, hipSetDevice(h->device));
-  HIPCHK(h, hipMemcpy(dst, h->packed_dev, (size_t)h->packed_floats * sizeof(float), hipMemcpyDeviceToDevice));
+  const int64_t n = flat_floats(h);
+  if (cap < n) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)n);
+  std::vector<float> tmp;
+  float* out = dst;
+  if (mem_kind != FILM_MEM_HOST) {
+    if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle has no device");
+    tmp.resize((size_t)n);
+    out = tmp.data();
+  }
+  int64_t off = 0;
+  for (const LayerPack& L : h->layers) {
+    const HostTensor& k = h->host_w.at(L.name + "/kernel");
+    const HostTensor& bq = h->host_w.at(L.name + "/bias");
+    memcpy(out + off, k.data.data(), k.data.size() * sizeof(float)); off += (int64_t)k.data.size();
+    memcpy(out + off, bq.data.data(), bq.data.size() * sizeof(float)); off += (int64_t)bq.data.size();
+  }
+  if (mem_kind != FILM_MEM_HOST) {
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(dst, tmp.data(), (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  }
   return FILM_OK;
 }
 
 int film_import_packed(film_t* h, const float* src, int64_t n, int mem_kind) {
   if (!h || !src) return FILM_ERR_INVALID;
-  if (n != h->packed_floats) return fail(h, FILM_ERR_INVALID, "blob has %lld floats, expected %lld", (long long)n, (long long)h->packed_floats);
-  h->packed_host.resize((size_t)n);
-  if (mem_kind == FILM_MEM_HOST) {
-    memcpy(h->packed_host.data(), src, (size_t)n * sizeof(float));
-  } else {
+  if (n != flat_floats(h)) return fail(h, FILM_ERR_INVALID, "blob has %lld floats, expected %lld", (long long)n, (long long)flat_floats(h));
+  std::vector<float> tmp;
+  const float* in = src;
+  if (mem_kind != FILM_MEM_HOST) {
     if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle has no device");
+    tmp.resize((size_t)n);
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpy(h->packed_host.data(), src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(tmp.data(), src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    in = tmp.data();
   }
-  int rc = upload_packed(h);
-  if (rc) return rc;
-  h->finalized = true;
+  int64_t off = 0;
+  for (const LayerPack& L : h->layers) {
+    HostTensor k, bq;
+    k.dims = {L.kh, L.kw, L.cin, L.cout};
+    k.data.assign(in + off, in + off + (int64_t)L.kh * L.kw * L.cin * L.cout); off += (int64_t)k.data.size();
+    bq.dims = {L.cout};
+    bq.data.assign(in + off, in + off + L.cout); off += L.cout;
+    h->host_w[L.name + "/kernel"] = std::move(k);
+    h->host_w[L.name + "/bias"] = std::move(bq);
+  }
+  return film_finalize(h);
+}
+
+// the kernel-layout blob (debug / tests): the packed prefix [0, *n)
+int film_export_layouts(film_t* h, float* dst, int64_t cap, int64_t* n) {
+  if (!h) return FILM_ERR_INVALID;
+  if (!h->finalized) return fail(h, FILM_ERR_STATE, "film_finalize has not been called");
+  if (n) *n = h->packed_floats;
+  if (!dst) return FILM_OK;
+  if (cap < h->packed_floats) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)h->packed_floats);
+  memcpy(dst, h->packed_host.data(), (size_t)h->packed_floats * sizeof(float));
   return FILM_OK;
 }
 
@@ -1467,6 +1586,10 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->last_plan = nullptr;
       h->opt_splitk = value != 0;
     }
+  }
+  else if (!strcmp(key, "pack_groups")) {
+    if (value < 1 || value > 4) return fail(h, FILM_ERR_INVALID, "pack_groups: 1 .. 4");
+    if (h->finalized) { int rc = film_ensure_groups_(h, (int)value); if (rc) return rc; }
   }
   else if (!strcmp(key, "fuse")) {
     if ((int)(value & 7) != h->opt_fuse) {  // plans carry the op list: drop them

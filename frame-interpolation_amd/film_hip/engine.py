@@ -42,7 +42,7 @@ class _Config(ctypes.Structure):
 # every symbol include/film_hip.h declares; tests assert the library exports all of them
 EXPORTED_SYMBOLS = (
     'film_default_config', 'film_create', 'film_destroy', 'film_last_error', 'film_set_weight',
-    'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_forward',
+    'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_export_layouts', 'film_forward',
     'film_interpolate',
     'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version')
 
@@ -80,6 +80,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_packed_size.argtypes = [vp, i64p]
     lib.film_export_packed.argtypes = [vp, fp, ctypes.c_int64, ctypes.c_int]
     lib.film_import_packed.argtypes = [vp, fp, ctypes.c_int64, ctypes.c_int]
+    lib.film_export_layouts.argtypes = [vp, fp, ctypes.c_int64, i64p]
     lib.film_forward.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, fp, ctypes.c_int, vp]
     lib.film_interpolate.argtypes = [vp, fp, fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, fp, ctypes.c_int, vp]
@@ -166,6 +167,14 @@ class FilmEngine:
     def export_packed(self) -> np.ndarray:
         out = np.empty(self.packed_size(), dtype=np.float32)
         self._check(self._lib.film_export_packed(self._h, out.ctypes.data, out.size, FILM_MEM_HOST))
+        return out
+
+    def export_layouts(self) -> np.ndarray:
+        """The kernel-layout blob packed so far (tests / debug; offsets as in plan())."""
+        n = ctypes.c_int64()
+        self._check(self._lib.film_export_layouts(self._h, None, 0, ctypes.byref(n)))
+        out = np.empty(n.value, dtype=np.float32)
+        self._check(self._lib.film_export_layouts(self._h, out.ctypes.data, out.size, ctypes.byref(n)))
         return out
 
     def import_packed(self, blob: np.ndarray) -> None:

@@ -82,11 +82,19 @@ int film_set_weight(film_t* h, const char* name, const float* data, const int64_
  * uploads the blob to the device. */
 int film_finalize(film_t* h);
 
-/* Packed weight blob (floats): size, export to / import from a caller buffer.  Import lets a
- * rank that received the blob by RCCL broadcast skip film_set_weight + repacking. */
+/* The parameter set as ONE flat blob of floats - per layer, in layer order, the HWIO kernel then the bias (137.7 MB for the
+ * published net): size, export to / import from a caller buffer.  This is what ranks exchange: rank 0 reads the model,
+ * the others receive the blob by RCCL broadcast and film_import_packed() it (= film_set_weight of every tensor +
+ * film_finalize).  Kernel layouts are built per handle, on demand: film_finalize packs what the default fp32 plan reads
+ * (K-major + F(4,3) + phase-summed 2x2 copies, 3.0x the parameters, multi-threaded, well under a second); the F(2,3), halo
+ * and bf16-split copies are packed when an option or a plan first needs them. */
 int film_packed_size(film_t* h, int64_t* n_floats);
 int film_export_packed(film_t* h, float* dst, int64_t capacity_floats, int mem_kind);
 int film_import_packed(film_t* h, const float* src, int64_t n_floats, int mem_kind);
+
+/* Debug / tests: the kernel-layout blob packed so far (offsets as in film_plan_json; "pack_groups" option packs more).
+ * dst == NULL: size query. */
+int film_export_layouts(film_t* h, float* dst, int64_t capacity_floats, int64_t* n_floats);
 
 /* Runs film_net on B frame pairs: x0, x1 [B,H,W,3] -> out [B,H,W,3] (un-clipped), t = 0.5.
  * H and W must be divisible by 2^(pyramid_levels-1) (options.py:36-37) - pad first, as
@@ -138,6 +146,8 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  (2-16 partial sums over K ranges, added in split order by a second kernel: deterministic, and the
  *                  factor depends on the level size and the layer only, never on the batch); it is what bounds the
  *                  latency of small frames.  Changing it drops the cached plans.
+ *   "pack_groups" n  pack (and upload) the weight layout groups 1..n now: 1 default fp32 layouts, 2 + F(2,3) copy, 3 + halo
+ *                  copy, 4 + bf16 split copies (normally packed on demand)
  *   "fuse"    bits 7 (default): small-launch fusion, identical arithmetic and bit-identical results.  1: tf.image.resize(2 * v)
  *                  of the flow estimator inside the warp kernels that consume it; 2: v = residual + upsampled flow inside
  *                  the flow-head kernels; 4: the 3-channel image warps of the t = 0.5 stage inside the feature warps of the

@@ -78,10 +78,18 @@ def test_set_weight_validation(tiny_weights):
     with pytest.raises(FilmError):   # finalize with tensors missing
         eng.set_weights({'fusion/output_conv/bias': np.zeros((3,), np.float32)})
     eng.set_weights(tiny_weights)
-    blob = eng.export_packed()
+    blob = eng.export_packed()                      # flat parameter blob: per layer the HWIO kernel, then the bias
+    assert blob.size == eng.packed_size() == sum(v.size for v in tiny_weights.values())
     eng2 = FilmEngine(TINY, device=-1)
     eng2.import_packed(blob)
     assert np.array_equal(eng2.export_packed(), blob)
+    # both handles build the same kernel layouts, group by group (default group first, all four on request)
+    assert np.array_equal(eng2.export_layouts(), eng.export_layouts())
+    n1 = eng.export_layouts().size
+    for e in (eng, eng2):
+        e.set_option('pack_groups', 4)
+    assert eng.export_layouts().size > 2 * n1 and np.array_equal(eng2.export_layouts(), eng.export_layouts())
+    assert np.array_equal(eng.export_layouts()[:n1], eng2.export_layouts()[:n1])
 
 
 def test_packing_permutes_fusion_inputs(tiny_weights):
@@ -91,7 +99,7 @@ def test_packing_permutes_fusion_inputs(tiny_weights):
     from film_hip.options import TINY
     eng = FilmEngine(TINY, device=-1)
     eng.set_weights(tiny_weights)
-    blob = eng.export_packed()
+    blob = eng.export_layouts()
     plan = eng.plan(1, 32, 32)
     L = {l['name']: l for l in plan['layers']}['fusion/convs_0_1']
     C = W.feature_channels(TINY)[0]
@@ -118,11 +126,12 @@ def test_plan_interpreter_matches_oracle_tiny(tiny_weights, b, h, w):
     import plan_interp as pi
     eng = FilmEngine(TINY, device=-1)
     eng.set_weights(tiny_weights)
+    eng.set_option('pack_groups', 4)     # every layout copy, so that the interpreter can check all of them
     plan = eng.plan(b, h, w)
     rng = np.random.default_rng(h * 7 + w)
     x0 = rng.random((b, h, w, 3), dtype=np.float32)
     x1 = rng.random((b, h, w, 3), dtype=np.float32)
-    arena = pi.run_plan(plan, eng.export_packed(), x0, x1)
+    arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
     want, aux = fo.film_forward(x0, x1, tiny_weights, oracle_options(TINY), return_aux=True)
     fc = W.feature_channels(TINY)
     for l in range(TINY.pyramid_levels):
@@ -147,11 +156,12 @@ def test_plan_interpreter_matches_oracle_published_64():
     w = W.make_synthetic_weights(PUBLISHED, seed=0)
     eng = FilmEngine(PUBLISHED, device=-1)
     eng.set_weights(w)
+    eng.set_option('pack_groups', 4)
     plan = eng.plan(1, 64, 64)
     rng = np.random.default_rng(3)
     x0 = rng.random((1, 64, 64, 3), dtype=np.float32)
     x1 = rng.random((1, 64, 64, 3), dtype=np.float32)
-    arena = pi.run_plan(plan, eng.export_packed(), x0, x1)
+    arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
     want = fo.film_forward(x0, x1, w, fo.Options())
     assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
     # algorithmic conv FLOPs of the plan == SURVEY.md 8(d): 4 246 240.6875 FLOP per padded pixel
