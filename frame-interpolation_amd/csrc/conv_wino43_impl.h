@@ -42,7 +42,7 @@ enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priori
        W43_F_PF2 = 32768 };    // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
-__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH) void conv_wino43_kernel(ConvParams p) {
+__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU
   constexpr int RPT = 32 / QW;                 // patch rows per 32-quad MFMA tile
   constexpr int MT = TH / RPT;                 // MFMA row tiles per patch; TM of them per wave
   constexpr int NU = 6 / NH;                   // nu planes per wave
@@ -298,6 +298,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
     constexpr int H = decltype(h_c)::value;
     float* const give = xbuf + (H * PW + pw) * XW + lane;
     const float* const take = xbuf + ((1 - H) * PW + pw) * XW + lane;
+    float keep[TM][TN][16];   // fused pool: the activated outputs of round 0
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
       if (round) __syncthreads();   // everybody has consumed round 0
@@ -321,12 +322,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
         const float bv = p.bias[n];
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
+          float val[16];
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row MFMA tile
             const int y = y0 + (wm + mt) * RPT + mrow / QW;
-            if (y >= p.H) continue;
-            const size_t rowbase = ((size_t)img * p.H + y) * p.W;
             const int x = x0 + 4 * (mrow % QW) + 2 * H + round;
             const float got = take[((mt * TN + nt) * 16 + r) * 64];
             const float ma = acc[mt][1][nt][r], mb = acc[mt][2][nt][r], m0 = acc[mt][0][nt][r];
@@ -335,7 +335,28 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
             else v = round == 0 ? got + 4.f * (m0 + ma) : got + (8.f * (m0 - ma) + mb);                  // y2, y3
             v += bv;
             if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-            if (x < p.W) p.out[(rowbase + x) * p.ostride + n] = v;
+            val[r] = v;
+            if (y < p.H && x < p.W) p.out[(((size_t)img * p.H + y) * p.W + x) * p.ostride + n] = v;
+          }
+          if constexpr (QW == 16) {
+            // fused 2x2 average pool: this lane holds rows 2k (r < 8) and 2k + 1 (r >= 8) of quad q = mrow % 16 at
+            // x = 4q + 2H (round 0, kept) and x + 1 (round 1)
+            if (p.pool_out != nullptr) {
+              if (round == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) keep[mt][nt][r] = val[r];
+              } else {
+                const int yp = (y0 >> 1) + wm + mt;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                  const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+                  const int xp = (x0 >> 1) + 2 * q + H;
+                  const float pv = (((keep[mt][nt][r] + val[r]) + keep[mt][nt][r + 8]) + val[r + 8]) * 0.25f;
+                  if (2 * yp < p.H && 2 * xp < p.W)
+                    p.pool_out[(((size_t)img * (p.H >> 1) + yp) * (p.W >> 1) + xp) * p.pool_ostride + n] = pv;
+                }
+              }
+            }
           }
         }
       }
@@ -348,25 +369,48 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH)
     // all six planes in this wave: the same sums, in the same order, as the two-half exchange above
     const int n = n0 + ng * 32 + l31;
     const float bv = p.bias[n];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int y = y0 + wm * RPT + mrow / QW;
-      if (y >= p.H) continue;
-      const size_t rowbase = ((size_t)img * p.H + y) * p.W;
-      const int x = x0 + 4 * (mrow % QW);
+    auto outputs = [&](int r, float* o) {
       const float m0 = acc[0][0][0][r], m1 = acc[0][1][0][r], m2 = acc[0][2][0][r], m3 = acc[0][3][0][r], m4 = acc[0][4][0][r],
                   m5 = acc[0][5][0][r];
-      float v[4];
-      v[0] = ((m0 + m1) + m2) + (m3 + m4);
-      v[1] = (m1 - m2) + 2.f * (m3 - m4);
-      v[2] = (m1 + m2) + 4.f * (m3 + m4);
-      v[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
+      o[0] = ((m0 + m1) + m2) + (m3 + m4);
+      o[1] = (m1 - m2) + 2.f * (m3 - m4);
+      o[2] = (m1 + m2) + 4.f * (m3 + m4);
+      o[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float o = v[j] + bv;
-        if (p.leaky) o = o > 0.f ? o : 0.2f * o;
-        if (x + j < p.W) p.out[(rowbase + x + j) * p.ostride + n] = o;
+        o[j] += bv;
+        if (p.leaky) o[j] = o[j] > 0.f ? o[j] : 0.2f * o[j];
+      }
+      const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int y = y0 + wm * RPT + mrow / QW;
+      const int x = x0 + 4 * (mrow % QW);
+      if (y < p.H) {
+        const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (x + j < p.W) p.out[(rowbase + x + j) * p.ostride + n] = o[j];
+      }
+    };
+    if (QW == 16 && p.pool_out != nullptr) {
+      const int yp = (y0 >> 1) + wm;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {      // rows 2k (r) and 2k + 1 (r + 8) of the same quad
+        float t[4], bq[4];
+        outputs(r, t);
+        outputs(r + 8, bq);
+        const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int xp = (x0 >> 1) + 2 * q + e;
+          const float pv = (((t[2 * e] + t[2 * e + 1]) + bq[2 * e]) + bq[2 * e + 1]) * 0.25f;
+          if (2 * yp < p.H && 2 * xp < p.W) p.pool_out[(((size_t)img * (p.H >> 1) + yp) * (p.W >> 1) + xp) * p.pool_ostride + n] = pv;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float o[4];
+        outputs(r, o);
       }
     }
   }

@@ -86,6 +86,7 @@ struct OpDesc {
   int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
+  View pack_b, pack_f, pack_out;   // warp: fused pack_flow (0.5 * flows into the aligned pyramid)
   View img_in, img_out;   // warp: fused 3-channel image warp with the same flow (t = 0.5 stage)
   View in3, out2;   // warp: coarser flow to upsample / the upsampled flow it stores; flow heads: in2 = upsampled flow, out2 = v = out + in2
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
@@ -169,7 +170,7 @@ struct film_handle {
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
-  int opt_fuse = 7;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
+  int opt_fuse = 15;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
@@ -628,7 +629,15 @@ struct Planner {
         SegDesc s1; s1.v = tmp;
         View dst = view(feat[lv], 0, slot_offset(c, j), k);
         conv(tg, w1, {s1}, dst, N2, HL(lv), WL(lv), true);
-        if (j < n - 1) pool(tg + ":pool", dst, scratch(fx_p, k), N2, HL(lv), WL(lv));
+        if (j < n - 1) {
+          OpDesc& cv = P->ops.back();
+          if ((h->opt_fuse & 8) && cv.kind == OP_CONV && cv.wino == 3 && !(HL(lv) & 1) && !(WL(lv) & 1)) {
+            // AveragePooling2D in the epilogue of the F(4,3) kernel (its 64-pixel tiles hold both rows of a 2x2 block)
+            cv.tag += "+pool";
+            cv.out2 = scratch(fx_p, k);
+          } else
+            pool(tg + ":pool", dst, scratch(fx_p, k), N2, HL(lv), WL(lv));
+        }
       }
       // every subtree but the level-0 one (75 % of the extractor's FLOPs) goes to the side stream: they and the coarse
       // flow levels that need only them are small, latency-bound launches that hide under the level-0 subtree
@@ -740,6 +749,13 @@ struct Planner {
         warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
              view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f, false);
       }
+      if (h->opt_fuse & 4) {   // 0.5 * flows ride in the second feature warp of the level
+        OpDesc& w = P->ops.back();
+        w.tag += "+flows";
+        w.pack_b = view(v[l], B, 0, 2);   // backward flow (d = 1)
+        w.pack_f = view(v[l], 0, 0, 2);   // forward flow  (d = 0)
+        w.pack_out = view(aligned[l], 0, 2 * fc[l] + 6, 10);
+      } else {
       OpDesc pk;
       pk.kind = OP_PACK_FLOW; pk.tag = tg + ":flows";
       pk.in = view(v[l], B, 0, 2);   // backward flow (d = 1)
@@ -747,6 +763,7 @@ struct Planner {
       pk.out = view(aligned[l], 0, 2 * fc[l] + 6, 10);
       pk.n = (int64_t)B * HL(l) * WL(l); pk.bytes = 4.0 * pk.n * 14;
       P->ops.push_back(pk);
+      }
     }
     for (size_t q = first_align_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
 
@@ -782,13 +799,15 @@ struct Planner {
   static bool overlap(const Access& a, const Access& b) { return a.buf == b.buf && a.c0 < b.c1 && b.c0 < a.c1; }
   void accesses(const OpDesc& op, std::vector<Access>& rd, std::vector<Access>& wr) const {
     rd.clear(); wr.clear();
-    if (op.kind == OP_CONV) for (int i = 0; i < op.nseg; ++i) rd.push_back(access(op.seg[i].v));
+    if (op.kind == OP_CONV) { for (int i = 0; i < op.nseg; ++i) rd.push_back(access(op.seg[i].v)); }
     else { if (op.in.buf >= 0) rd.push_back(access(op.in)); if (op.in2.buf >= 0) rd.push_back(access(op.in2)); }
     if (op.in3.buf >= 0) rd.push_back(access(op.in3));
     if (op.img_in.buf >= 0) rd.push_back(access(op.img_in));
+    if (op.pack_b.buf >= 0) { rd.push_back(access(op.pack_b)); rd.push_back(access(op.pack_f)); }
     if (op.out.buf >= 0) wr.push_back(access(op.out));
     if (op.out2.buf >= 0) wr.push_back(access(op.out2));
     if (op.img_out.buf >= 0) wr.push_back(access(op.img_out));
+    if (op.pack_out.buf >= 0) wr.push_back(access(op.pack_out));
   }
   // For every op: the LAST op of the other lane it conflicts with (RAW, WAR or WAW on overlapping channels of a
   // buffer).  Waiting for the last one is enough: a lane executes in program order.
@@ -841,6 +860,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.M = op.NB * op.H * op.W;
       p.fold = op.fold; p.py = op.py; p.px = op.px; p.ftaps = op.ftaps;
       p.ksplit = op.ksplit; p.part = op.ksplit > 1 ? arena + op.part_off : nullptr;
+      if (op.out2.buf >= 0) { p.pool_out = mptr(arena, op.out2); p.pool_ostride = op.out2.stride; }
       for (int q = 0; q < 4; ++q) { p.tdy[q] = (signed char)op.tdy[q]; p.tdx[q] = (signed char)op.tdx[q]; p.fold_woff[q] = op.fold_woff[q]; }
       return film_launch_conv(p, op.tile, s);
     }
@@ -888,6 +908,10 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.src3 = cptr(arena, op.img_in); p.s3stride = op.img_in.stride;
         p.dst3 = mptr(arena, op.img_out); p.d3stride = op.img_out.stride;
       }
+      if (op.pack_out.buf >= 0) {
+        p.pack_b = cptr(arena, op.pack_b); p.pack_f = cptr(arena, op.pack_f);
+        p.pack_dst = mptr(arena, op.pack_out); p.pack_stride = op.pack_out.stride;
+      }
       return film_launch_warp(p, s);
     }
     case OP_PACK_FLOW: {
@@ -933,14 +957,17 @@ std::vector<int> wino_candidates(int Cout) {
   return out;
 }
 
-std::vector<int> wino43_candidates(int Cout) {
+std::vector<int> wino43_candidates(int Cout, bool pool = false) {
   // the 64-pixel ("Q16", two workgroups per CU) tiles won every layer of the 1080p plan against the 128-pixel ones
   // (profiles/r02_conv_bench_w43.log); one 128-pixel tile stays in the list for shapes nobody measured
   std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11, W43_Q16_4x64_N1,
                                                               W43_Q16_4x64_T21_P2, W43_Q16_4x64_T12_P2, W43_Q16_4x32_T11_P2, W43_Q16_4x64_N1_P2}
                                             : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11, W43_Q16_4x32_T11_P2};
   std::vector<int> out;
-  for (int sh : shapes) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD); }
+  for (int sh : shapes) {
+    if (pool && (sh == W43_4x64_T21 || sh == W43_4x64_T12 || sh == W43_4x32_T11)) continue;   // the fused pool needs a 64-pixel tile
+    out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD);
+  }
   return out;
 }
 
@@ -978,7 +1005,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << ':' << op.ksplit;
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << ':' << op.ksplit << ':' << (op.out2.buf >= 0);
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -1004,7 +1031,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         cands.clear();
         for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
@@ -1147,6 +1174,9 @@ std::string plan_json(film_t* h, const Plan& P) {
     json_view(o, "out2", op.out2, P); o << ",";
     json_view(o, "img_in", op.img_in, P); o << ",";
     json_view(o, "img_out", op.img_out, P); o << ",";
+    json_view(o, "pack_b", op.pack_b, P); o << ",";
+    json_view(o, "pack_f", op.pack_f, P); o << ",";
+    json_view(o, "pack_out", op.pack_out, P); o << ",";
     json_view(o, "out", op.out, P);
     o << ",\"segs\":[";
     for (int k = 0; k < op.nseg; ++k) {
@@ -1592,12 +1622,12 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     if (h->finalized) { int rc = film_ensure_groups_(h, (int)value); if (rc) return rc; }
   }
   else if (!strcmp(key, "fuse")) {
-    if ((int)(value & 7) != h->opt_fuse) {  // plans carry the op list: drop them
+    if ((int)(value & 15) != h->opt_fuse) {  // plans carry the op list: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
       h->plans.clear();
       h->last_plan = nullptr;
-      h->opt_fuse = (int)(value & 7);
+      h->opt_fuse = (int)(value & 15);
     }
   }
   else if (!strcmp(key, "fold2x2")) {

@@ -55,6 +55,12 @@ struct ConvParams {
   // K loop (up to 1080 steps) otherwise runs on a handful of workgroups.
   int ksplit;
   float* part;
+  // Fused AveragePooling2D(2, 2) of the output (feature_extractor.py:138-146: every sub-extractor stage but the last
+  // is followed by a pool), conv_wino43_kernel's 64-pixel tiles only: the epilogue also writes
+  // pool_out[img][y/2][x/2][n] = (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25 (pool_vec_kernel's order) from
+  // the activated outputs it holds in registers - the former pool launch and its re-read of the feature map.  H, W even.
+  float* pool_out;    // nullptr: none
+  int pool_ostride;
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,
@@ -137,6 +143,11 @@ struct WarpParams {
   int s3stride;
   float* dst3;
   int d3stride;
+  // Fused pack_flow (PackFlowParams) for the same pixels: pack_dst[pix] = {0.5 bflow, 0.5 fflow, 0 x 6}; nullptr: none.
+  const float* pack_b;
+  const float* pack_f;
+  float* pack_dst;
+  int pack_stride;
 };
 
 // Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:

@@ -257,9 +257,27 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   if (i >= nfeat) {
     // image units of the band (behind its feature units; only the last workgroups have any): one thread = one pixel
     // of one row of the band, 3 channels
-    if (p.src3 == nullptr || i - nfeat >= (unsigned)(p.W * WARP_ROWS)) return;
+    const unsigned band = (unsigned)(p.W * WARP_ROWS);
+    unsigned u = i - nfeat;
+    if (p.src3 == nullptr || u >= band) {
+      // flow-packing units (behind the image units): one thread = one pixel
+      if (p.src3 != nullptr) u -= band;
+      if (p.pack_dst == nullptr || u >= band) return;
+      int k, x;
+      split_unit(u, p.W, k, x);
+      if (yb + k >= p.H) return;
+      const int64_t pix = (b * p.H + yb + k) * p.W + x;
+      const float2 bf = reinterpret_cast<const float2*>(p.pack_b)[pix];
+      const float2 ff = reinterpret_cast<const float2*>(p.pack_f)[pix];
+      float* d = p.pack_dst + pix * p.pack_stride;
+      d[0] = bf.x * 0.5f; d[1] = bf.y * 0.5f;
+      d[2] = ff.x * 0.5f; d[3] = ff.y * 0.5f;
+#pragma unroll
+      for (int q = 4; q < 10; ++q) d[q] = 0.f;
+      return;
+    }
     int k, x;
-    split_unit(i - nfeat, p.W, k, x);
+    split_unit(u, p.W, k, x);
     const int y = yb + k;
     if (y >= p.H) return;
     const float2 fl = warp_flow_at(p, b, y, x);
@@ -413,10 +431,10 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
   if (units >= (1 << 24) || p.H > 65535 || p.NB > 65535) return hipErrorInvalidValue;
   if (p.coarse != nullptr && ((p.H | p.W) & 1)) return hipErrorInvalidValue;
   if (p.C == 3) {
-    if (p.flow_out != nullptr || p.src3 != nullptr) return hipErrorInvalidValue;
+    if (p.flow_out != nullptr || p.src3 != nullptr || p.pack_dst != nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(warp_c3_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB), dim3(256), 0, s, p);
   } else {
-    const int64_t all = units + (p.src3 != nullptr ? (int64_t)p.W * WARP_ROWS : 0);
+    const int64_t all = units + ((p.src3 != nullptr) + (p.pack_dst != nullptr)) * (int64_t)p.W * WARP_ROWS;
     hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)((all + 255) / 256), (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB),
                        dim3(256), 0, s, p);
   }

@@ -140,6 +140,9 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             _view(arena, op['out'], nb, h, w)[...] = y
+            if op.get('out2', {}).get('buf'):       # fused AveragePooling2D(2, 2) of the output
+                assert op.get('wino') == 3 and h % 2 == 0 and w % 2 == 0
+                _view(arena, op['out2'], nb, h // 2, w // 2)[...] = fo.avg_pool2x2(y)
         elif k == 'flow_head':
             m = op['n']
             x = np.ascontiguousarray(_view(arena, op['in'], 1, 1, m))
@@ -186,6 +189,11 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             if op.get('img_in', {}).get('buf'):     # fused 3-channel image warp with the same flow
                 im = np.ascontiguousarray(_view(arena, op['img_in'], nb, h, w))
                 _view(arena, op['img_out'], nb, h, w)[...] = fo.warp(im, np.float32(op['fscale']) * flow)
+            if op.get('pack_out', {}).get('buf'):   # fused pack_flow
+                out = _view(arena, op['pack_out'], nb, h, w)
+                out[..., 0:2] = _view(arena, op['pack_b'], nb, h, w) * np.float32(0.5)
+                out[..., 2:4] = _view(arena, op['pack_f'], nb, h, w) * np.float32(0.5)
+                out[..., 4:10] = 0
         elif k == 'pack_flow':
             m = op['n']
             bf = _view(arena, op['in'], 1, 1, m)

@@ -273,8 +273,9 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
 
         def rw(op):
             rd = [acc(sg['v']) for sg in op.get('segs', [])] if op['kind'] == 'conv_mfma' else [acc(op.get('in')), acc(op.get('in2'))]
-            rd += [acc(op.get('in3')), acc(op.get('img_in'))]
-            return [a for a in rd if a], [a for a in [acc(op.get('out')), acc(op.get('out2')), acc(op.get('img_out'))] if a]
+            rd = list(rd)
+            rd += [acc(op.get('in3')), acc(op.get('img_in')), acc(op.get('pack_b')), acc(op.get('pack_f'))]
+            return [a for a in rd if a], [a for a in [acc(op.get('out')), acc(op.get('out2')), acc(op.get('img_out')), acc(op.get('pack_out'))] if a]
 
         def hit(a, b):
             return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
@@ -303,3 +304,34 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
                     any(hit(r, w2) for r in ri for w2 in wj)
                 if conflict:
                     assert i in before[j], (ops[i]['tag'], ops[j]['tag'])
+
+
+def test_plan_interpreter_fused_ops_published_256():
+    """The default plan of a 256x256 pair carries every fusion (fuse = 15): flow upsample inside the warps, v = res + up
+    inside the flow heads, image warps inside the feature warps, average pools inside the F(4,3) convolutions - and the
+    interpreter, which gives each fused op the semantics of the separate reference ops, still reproduces the oracle.
+    With fuse = 0 the plan has one op per reference op and the same result."""
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED
+    from oracle import film_oracle as fo
+    import plan_interp as pi
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    rng = np.random.default_rng(9)
+    x0 = rng.random((1, 256, 256, 3), dtype=np.float32)
+    x1 = rng.random((1, 256, 256, 3), dtype=np.float32)
+    want = fo.film_forward(x0, x1, w, fo.Options())
+    counts = {}
+    for fuse in (15, 0):
+        eng = FilmEngine(PUBLISHED, device=-1)
+        eng.set_weights(w)
+        eng.set_option('fuse', fuse)
+        eng.set_option('pack_groups', 4)     # the interpreter checks every weight copy an op could read
+        plan = eng.plan(1, 256, 256)
+        tags = [op['tag'] for op in plan['ops']]
+        counts[fuse] = len(tags)
+        for mark in ('+pool', '+img', '+flows', '+resize2x', '+v=res+up'):
+            assert any(mark in t for t in tags) == (fuse == 15), (fuse, mark)
+        arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
+        assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
+    assert counts[0] - counts[15] >= 25, counts
