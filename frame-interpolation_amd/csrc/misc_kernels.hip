@@ -66,13 +66,21 @@ __global__ __launch_bounds__(256) void flow_head_kernel(FlowHeadParams p) {
   float h[16];
 #pragma unroll
   for (int o = 0; o < 16; ++o) h[o] = 0.f;
-  for (int c = 0; c < p.Cin; c += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(src + c);
-    const float vv[4] = {v.x, v.y, v.z, v.w};
+  // 32 input channels at a time: the eight 16-byte loads of a pixel are requested together (one memory latency per
+  // 32 channels instead of one per 4; this kernel is latency bound: 544 fmas per 136 bytes)
+  for (int c0 = 0; c0 < p.Cin; c0 += 32) {
+    float4 v[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int q = 0; q < 8; ++q) v[q] = c0 + 4 * q < p.Cin ? *reinterpret_cast<const float4*>(src + c0 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int o = 0; o < 16; ++o) h[o] = __builtin_fmaf(vv[k], wsm[(c + k) * 16 + o], h[o]);
+    for (int q = 0; q < 8; ++q) {
+      if (c0 + 4 * q >= p.Cin) break;
+      const float vv[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int o = 0; o < 16; ++o) h[o] = __builtin_fmaf(vv[k], wsm[(c0 + 4 * q + k) * 16 + o], h[o]);
+      }
     }
   }
   float o0 = 0.f, o1 = 0.f;

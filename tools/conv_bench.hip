@@ -14,12 +14,10 @@
 #include <vector>
 
 #include "../frame-interpolation_amd/csrc/conv_igemm_impl.h"
-#include "experiments/conv_dma_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_split_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_winox3_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino43_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino_impl.h"
-#include "experiments/conv_wino16_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_halo_impl.h"
 
@@ -55,11 +53,9 @@ __global__ void checksum_kernel(const float* a, size_t n, double* out) {
 typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
 struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  // wkind 0: [K][N]  1: [N][K]  2: [N][chunk][tap][16]
 #define V(BM, BN, WM, WN, BKC, FL) {#BM "x" #BN " w" #WM "x" #WN " bk" #BKC " f" #FL, BM, BN, BKC, 0, conv_igemm_launch<BM, BN, WM, WN, BKC, FL>}
-#define D(BM, BN, WM, WN, FL) {"dma " #BM "x" #BN " w" #WM "x" #WN " f" #FL, BM, BN, 16, 1, conv_dma_launch<BM, BN, WM, WN, FL>}
 
 #define B(BM, BN, WM, WN, FL) {"buf " #BM "x" #BN " w" #WM "x" #WN " f" #FL, BM, BN, 16, 1, conv_buf_launch<BM, BN, WM, WN, FL>}
 #define H(TH, BN, WM, WN, FL) {"halo " #TH "x32x" #BN " w" #WM "x" #WN " f" #FL, TH * 32, BN, 16, 2, conv_halo_launch<TH, BN, WM, WN, FL>}
-#define W(TH, BN, WM, WN) {"wino16 " #TH "x64x" #BN " w" #WM "x" #WN " f4", TH * 64, BN, 16, 4, conv_wino16_launch<TH, BN, WM, WN, 4>}
 #define W8(TH, BN, WM, WN) {"wino " #TH "x64x" #BN " w" #WM "x" #WN " f4", TH * 64, BN, 8, 5, conv_wino_launch<TH, BN, WM, WN, 4>}
 #define X(TH, BN, TM, TN) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f4", TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, 4>}
 #define XA(TH, BN, TM, TN, FL) {"winox3 " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 16, 6, conv_winox3_launch<TH, BN, TM, TN, FL>}
@@ -70,7 +66,6 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
     V(128, 128, 2, 2, 16, 4), B(128, 128, 2, 2, 4),
-    W(4, 128, 4, 2), W(4, 64, 4, 1), W(4, 64, 4, 2), W(2, 128, 2, 2), W(4, 32, 4, 1),
     W8(4, 64, 4, 2), W8(4, 128, 4, 2), W8(4, 128, 4, 4), W8(4, 32, 4, 1), W8(8, 64, 8, 2), W8(8, 32, 8, 1), W8(2, 64, 2, 2),
     F43(4, 64, 1, 2), F43(4, 64, 2, 1), F43(4, 32, 1, 1), F43F(4, 64, 2, 1, 68), F43F(4, 64, 2, 1, 0),
     F43Q(4, 64, 2, 1, 4), F43Q(4, 64, 1, 2, 4), F43Q(4, 32, 1, 1, 4), F43Q(4, 64, 2, 1, 0),
@@ -81,15 +76,11 @@ static Variant variants[] = {
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
     H(4, 128, 2, 2, 4), H(8, 64, 2, 2, 4), B(256, 64, 4, 1, 4), B(128, 64, 2, 2, 4), B(64, 64, 2, 2, 4),
     B(256, 128, 4, 2, 4), B(256, 32, 4, 1, 4), B(128, 32, 4, 1, 4),
-    D(128, 128, 2, 2, 4), D(128, 128, 2, 2, 0),
-    D(128, 128, 2, 2, 68), D(128, 128, 2, 2, 132), D(128, 128, 2, 2, 260), D(128, 128, 2, 2, 388), D(128, 128, 2, 2, 324),
-    D(64, 64, 1, 1, 4), D(64, 64, 1, 1, 68), D(64, 64, 1, 1, 132),
-    V(128, 128, 2, 2, 16, 2052), V(128, 128, 2, 2, 16, 4100), V(128, 128, 2, 2, 16, 1028), D(128, 128, 2, 2, 1028),  // ablation: all A gathers from one pixel
-    V(128, 128, 2, 2, 16, 68),   // ablation: no global loads / LDS stores in the loop
-    V(128, 128, 2, 2, 16, 452),  // ablation: pure MFMA loop
-    V(256, 64, 4, 1, 16, 4),  D(256, 64, 4, 1, 4),
-    D(128, 64, 2, 2, 4), D(64, 64, 2, 2, 4), D(256, 128, 4, 2, 4), D(128, 256, 2, 4, 4),
-    V(256, 32, 4, 1, 16, 4),  D(256, 32, 4, 1, 4), D(128, 32, 4, 1, 4),
+    V(128, 128, 2, 2, 16, 2052), V(128, 128, 2, 2, 16, 4100), V(128, 128, 2, 2, 16, 1028),
+    V(128, 128, 2, 2, 16, 68),
+    V(128, 128, 2, 2, 16, 452),
+    V(256, 64, 4, 1, 16, 4),
+    V(256, 32, 4, 1, 16, 4),
 };
 
 // [tap*C + c][N] -> [N][chunk][tap][16]
@@ -260,7 +251,7 @@ int main(int argc, char** argv) {
       if (only_variant && !strstr(v.name, only_variant)) continue;
       CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
       if (v.wkind >= 2 && sh.ks != 3) continue;
-      p.w = v.wkind == 7 ? d_w43 : v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 4 ? d_ww : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
+      p.w = v.wkind == 7 ? d_w43 : v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
       CK(v.fn(p, st));  // warm + correctness
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
       hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
