@@ -174,3 +174,38 @@ def test_interpolator_cli_writes_reference_frames(published, tmp_path, monkeypat
     for f, wnt in zip(files, want):
         got = util.read_image(str(d / 'interpolated_frames' / f))
         assert np.array_equal(util.to_uint8(wnt), (got * 255 + 0.5).astype(np.uint8)), f
+
+
+def test_eval_cli_on_vimeo_sized_triplets(published, tmp_path):
+    """eval.eval_cli end to end on the GPU - a model directory on disk (film_weights.npz) loaded by
+    Interpolator(model_path), two Vimeo-90K-sized triplet folders (448x256, im1/im2/im3.png), results.csv with
+    l1 / l2 / ssim / psnr per example and the mean row; the numbers against the same metrics of the oracle's prediction."""
+    from eval import eval_cli, metrics as M, util
+    from film_hip import weights as W
+    from oracle import film_oracle as fo
+    opt, w, _ = published
+    model_dir = tmp_path / 'model'
+    W.save_weights(str(model_dir), w)
+    root = tmp_path / 'vimeo'
+    truth = {}
+    for k, seq in enumerate(('00001/0001', '00001/0002')):
+        x0, x1 = TI.frame_pair(1, 256, 448, seed=20 + k, shift=(4, -6), fg_shift=(-3, 5))
+        mid, _ = TI.frame_pair(1, 256, 448, seed=20 + k, shift=(2, -3), fg_shift=(-2, 3))   # any plausible ground truth
+        d = root / seq
+        os.makedirs(d)
+        for name, img in (('im1.png', x0[0]), ('im2.png', mid[0]), ('im3.png', x1[0])):
+            util.write_image(str(d / name), img)
+        truth[seq.replace('/', '_')] = tuple(util.read_image(str(d / n)) for n in ('im1.png', 'im2.png', 'im3.png'))
+    out = tmp_path / 'out'
+    assert eval_cli.main(['--model_path', str(model_dir), '--triplet_dir', str(root), '--output_dir', str(out), '--output_frames']) == 0
+    rows = [l.strip().split(', ') for l in open(out / 'results.csv')]
+    assert rows[0] == ['key', 'l1', 'l2', 'ssim', 'psnr'] and [r[0] for r in rows[1:]] == ['00001_0001', '00001_0002', 'mean']
+    orc = fo.OracleInterpolator(w, align=64)
+    for r in rows[1:3]:
+        a, y, b = truth[r[0]]
+        pred = np.clip(orc(a[None], b[None], None), 0.0, 1.0)
+        want = [M.l1(pred, y[None]), M.l2(pred, y[None]), M.ssim(pred, y[None]), M.psnr(pred, y[None])]
+        got = [float(v) for v in r[1:]]
+        print(r[0], 'hip', got, 'oracle', want)
+        assert np.allclose(got[:3], want[:3], rtol=0, atol=2e-6) and abs(got[3] - want[3]) < 2e-3   # dB
+    assert sorted(os.listdir(out))[:4] == ['00001_0001_image.png', '00001_0001_x0.png', '00001_0001_x1.png', '00001_0001_y.png']
