@@ -641,7 +641,11 @@ struct Planner {
       }
       // every subtree but the level-0 one (75 % of the extractor's FLOPs) goes to the side stream: they and the coarse
       // flow levels that need only them are small, latency-bound launches that hide under the level-0 subtree
-      if (i >= 1) for (size_t q = first_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
+      // Small frames are latency bound: the flow chain l6 -> l0 can only start when the coarse subtrees (3..6) are done,
+      // so those go first on the side stream while the main stream works through subtrees 0, 1, 2 (256x256: level-3 flow
+      // starts after ~1.0 ms instead of ~1.5 ms).  Large frames keep subtrees 1.. on the side stream (tail filling).
+      const int side_from = (int64_t)H * W <= 512 * 512 ? 3 : 1;
+      if (i >= side_from) for (size_t q = first_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
     }
 
     // ---- bidirectional coarse-to-fine flow (pyramid_flow_estimator.py:125-163) ---------------------
