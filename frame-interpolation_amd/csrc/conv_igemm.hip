@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
   *reinterpret_cast<float4*>(out + (size_t)m * ostride + g * 4) = a;
 }
 
-hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
+static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
   if (p.pool_out != nullptr && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
   if (tile & CONV_TILE_FOLDX3) {
@@ -188,7 +188,15 @@ hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   }
   if (tile & CONV_TILE_C3)
     return (tile & CONV_TILE_XCD) ? launch_c3<CONV_F_XCD_M>(p, shape, s) : launch_c3<0>(p, shape, s);
-  const hipError_t e = (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
+  return (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
+}
+
+hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
+  // split-K is implemented by conv_buf_kernel and conv_wino43_kernel only
+  const bool can_split = !(tile & (CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
+                         (!(tile & CONV_TILE_WINO) || (tile & CONV_TILE_F43));
+  if (p.ksplit > 1 && !can_split) return hipErrorInvalidValue;
+  const hipError_t e = film_launch_conv_main(p, tile, s);
   if (e != hipSuccess || p.ksplit <= 1) return e;
   if (!p.part || (p.Cout & 3) || (long long)p.M * (p.Cout >> 2) >= (1ll << 32)) return hipErrorInvalidValue;
   const unsigned units = (unsigned)p.M * (unsigned)(p.Cout >> 2);

@@ -119,6 +119,10 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   // ---- B staging ---------------------------------------------------------------------------------------------------
   const int nkc = p.Ctot / 8;
   const int nstage = nkc * 3;    // (chunk, dy)
+  // split-K (ConvParams::ksplit, film_kernels.h): blockIdx.z = split s sums the K chunks [kbeg, kend) and writes raw partial
+  // sums to part[s][pixel][Cout]; conv_splitk_reduce_kernel adds them in split order with the bias and the activation
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+  const int kbeg = (int)((long long)nkc * blockIdx.z / ksp), kend = (int)((long long)nkc * (blockIdx.z + 1) / ksp);
   const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
   unsigned boff[BLD];
   int blds[BLD];
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<bf4*>(As + nu * A_PLANE) = v[nu];   // nu planes: QW rows x 8 floats apart
   };
   auto next_chunk = [&](int kc_next) {
-    if (kc_next >= nkc) { chunk_ok = false; return; }
+    if (kc_next >= kend) { chunk_ok = false; return; }
     c0 += 8;
     if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
   };
@@ -226,16 +230,21 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
+  for (int skip = kbeg * 8; skip > 0;) {   // first chunk of this split: walk the concat segments
+    const int cseg = p.seg[sg].C;
+    if (skip >= cseg) { skip -= cseg; ++sg; } else { c0 = skip; skip = 0; }
+  }
   setup_seg();
+  const int sb = kbeg * 3;
   load_item(C0{});    // every request of the prologue first, then the stores: one load latency instead of three
-  load_b(0, 0);
-  load_b(1, 1);
-  load_b(2, 2);
-  if constexpr (PF2) { next_chunk(1); load_item(C1{}); }   // chunk 1 stays in registers until chunk 0's dy = 1 stage
+  load_b(sb + 0, 0);
+  load_b(sb + 1, 1);
+  load_b(sb + 2, 2);
+  if constexpr (PF2) { next_chunk(kbeg + 1); load_item(C1{}); }   // chunk 1 stays in registers until chunk 0's dy = 1 stage
   store_item(0, C0{});
   store_b(0, 0);
   store_b(1, 1);
-  next_chunk(PF2 ? 2 : 1);
+  next_chunk(kbeg + (PF2 ? 2 : 1));
   __syncthreads();
   fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur);
   int a_stage = 0;
@@ -280,12 +289,12 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     a_cur = a_next;
   };
   if constexpr (PF2) {
-    for (int kc = 0; kc < nkc; kc += 2) {
+    for (int kc = kbeg; kc < kend; kc += 2) {
       chunk(kc, C0{});
-      if (kc + 1 < nkc) chunk(kc + 1, C1{});
+      if (kc + 1 < kend) chunk(kc + 1, C1{});
     }
   } else {
-    for (int kc = 0; kc < nkc; ++kc) chunk(kc, C0{});
+    for (int kc = kbeg; kc < kend; ++kc) chunk(kc, C0{});
   }
 
   // ---- epilogue: y0 = (m0+m1+m2) + (m3+m4), y1 = (m1-m2) + 2(m3-m4) on half 0; y2 = (m1+m2) + 4(m3+m4),
@@ -333,6 +342,10 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
             float v;
             if (H == 0) v = round == 0 ? ((m0 + ma) + mb) + got : (ma - mb) + got;                       // y0, y1
             else v = round == 0 ? got + 4.f * (m0 + ma) : got + (8.f * (m0 - ma) + mb);                  // y2, y3
+            if (ksp > 1) {   // split-K: raw partial sum; bias, activation and the sum over the splits in the reduce kernel
+              if (y < p.H && x < p.W) p.part[((size_t)blockIdx.z * p.M + ((size_t)img * p.H + y) * p.W + x) * p.Cout + n] = v;
+              continue;
+            }
             v += bv;
             if (p.leaky) v = v > 0.f ? v : 0.2f * v;
             val[r] = v;
@@ -341,7 +354,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
           if constexpr (QW == 16) {
             // fused 2x2 average pool: this lane holds rows 2k (r < 8) and 2k + 1 (r >= 8) of quad q = mrow % 16 at
             // x = 4q + 2H (round 0, kept) and x + 1 (round 1)
-            if (p.pool_out != nullptr) {
+            if (p.pool_out != nullptr && ksp == 1) {
               if (round == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) keep[mt][nt][r] = val[r];
@@ -376,14 +389,23 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       o[1] = (m1 - m2) + 2.f * (m3 - m4);
       o[2] = (m1 + m2) + 4.f * (m3 + m4);
       o[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
+      const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+      const int y = y0 + wm * RPT + mrow / QW;
+      const int x = x0 + 4 * (mrow % QW);
+      if (ksp > 1) {   // split-K: raw partial sums
+        if (y < p.H) {
+          const size_t pix = ((size_t)img * p.H + y) * p.W + x;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (x + j < p.W) p.part[((size_t)blockIdx.z * p.M + pix + j) * p.Cout + n] = o[j];
+        }
+        return;
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         o[j] += bv;
         if (p.leaky) o[j] = o[j] > 0.f ? o[j] : 0.2f * o[j];
       }
-      const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int y = y0 + wm * RPT + mrow / QW;
-      const int x = x0 + 4 * (mrow % QW);
       if (y < p.H) {
         const size_t rowbase = ((size_t)img * p.H + y) * p.W;
 #pragma unroll
@@ -391,7 +413,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
           if (x + j < p.W) p.out[(rowbase + x + j) * p.ostride + n] = o[j];
       }
     };
-    if (QW == 16 && p.pool_out != nullptr) {
+    if (QW == 16 && p.pool_out != nullptr && ksp == 1) {
       const int yp = (y0 >> 1) + wm;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {      // rows 2k (r) and 2k + 1 (r + 8) of the same quad
@@ -433,7 +455,7 @@ hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
     }
   }
   const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
-  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN);
+  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();
 }

@@ -508,6 +508,20 @@ struct Planner {
         op.part_off = P->bufs[sb].off;
       }
     }
+    // Split-K for the F(4,3) kernel on levels whose workgroup count does not fill the 512 workgroup slots of the chip
+    // evenly: a 72x120 level with 512 output channels is 1152 workgroups = 2.25 rounds, the last one on a quarter of
+    // the CUs for the full duration of a deep K loop.  Two K ranges double the workgroup count at half the length; the partial sums are added in split order by conv_splitk_reduce_kernel.  Factor from
+    // the level size and the layer only.
+    if (h->opt_splitk && op.wino == 3 && L.cout % 4 == 0) {
+      // measured (profiles/r02_per_op_profile.json vs the run before): -10 % on the K = 2448 / 1920 layers of the 120-wide
+      // level, +7..10 % on its K <= 512 layers (reduce kernel + twice the prologues / epilogues) -> deep K only
+      int S = (ctot >= 1024 && px <= 16384) ? 2 : 1;
+      if (S > 1) {
+        op.ksplit = S;
+        const int sb = add_scratch("splitk:" + op.tag, (int64_t)S * M * L.cout);
+        op.part_off = P->bufs[sb].off;
+      }
+    }
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
     P->ops.push_back(op);
@@ -631,7 +645,7 @@ struct Planner {
         conv(tg, w1, {s1}, dst, N2, HL(lv), WL(lv), true);
         if (j < n - 1) {
           OpDesc& cv = P->ops.back();
-          if ((h->opt_fuse & 8) && cv.kind == OP_CONV && cv.wino == 3 && !(HL(lv) & 1) && !(WL(lv) & 1)) {
+          if ((h->opt_fuse & 8) && cv.kind == OP_CONV && cv.wino == 3 && cv.ksplit <= 1 && !(HL(lv) & 1) && !(WL(lv) & 1)) {
             // AveragePooling2D in the epilogue of the F(4,3) kernel (its 64-pixel tiles hold both rows of a 2x2 block)
             cv.tag += "+pool";
             cv.out2 = scratch(fx_p, k);
