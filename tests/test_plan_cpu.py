@@ -127,7 +127,10 @@ def test_plan_interpreter_matches_oracle_tiny(tiny_weights, b, h, w):
     eng = FilmEngine(TINY, device=-1)
     eng.set_weights(tiny_weights)
     eng.set_option('pack_groups', 4)     # every layout copy, so that the interpreter can check all of them
+    if (b, h, w) == (2, 32, 48):
+        eng.set_option('fuse', 0)        # one op per reference op (flow_up / flow_add / warp_c3 / pack_flow / pool launches)
     plan = eng.plan(b, h, w)
+    assert any(op['kind'] == 'flow_up' for op in plan['ops']) == ((b, h, w) == (2, 32, 48))
     rng = np.random.default_rng(h * 7 + w)
     x0 = rng.random((b, h, w, 3), dtype=np.float32)
     x1 = rng.random((b, h, w, 3), dtype=np.float32)
@@ -332,6 +335,7 @@ def test_plan_interpreter_fused_ops_published_256():
         counts[fuse] = len(tags)
         for mark in ('+pool', '+img', '+flows', '+resize2x', '+v=res+up'):
             assert any(mark in t for t in tags) == (fuse == 15), (fuse, mark)
-        arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
-        assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
+        if fuse == 15:      # (an unfused plan is interpreted by test_plan_interpreter_matches_oracle_tiny[2-32-48])
+            arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
+            assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
     assert counts[0] - counts[15] >= 25, counts
