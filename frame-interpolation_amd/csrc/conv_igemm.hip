@@ -31,6 +31,7 @@
 #include "conv_winox3_impl.h"
 #include "conv_foldx3_impl.h"
 #include "conv_igemm_impl.h"
+#include "conv_c3_impl.h"
 
 template <int F>
 static hipError_t launch_shape(const ConvParams& p, int shape, hipStream_t s) {
@@ -54,6 +55,7 @@ static hipError_t launch_c3(const ConvParams& p, int shape, hipStream_t s) {
     case TILE_128x64: return conv_igemm_launch<128, 64, 2, 2, 16, F | CONV_F_C3>(p, s);
     case TILE_256x32: return conv_igemm_launch<256, 32, 4, 1, 16, F | CONV_F_C3>(p, s);
     case TILE_128x32: return conv_igemm_launch<128, 32, 4, 1, 16, F | CONV_F_C3>(p, s);
+    case TILE_C3_DIRECT: return p.Cout == 64 ? conv_c3_launch<64>(p, s) : p.Cout == 32 ? conv_c3_launch<32>(p, s) : hipErrorInvalidValue;
     default: return hipErrorInvalidValue;
   }
 }

@@ -633,7 +633,7 @@ struct Planner {
           op.ksize = 3; op.leaky = 1; op.Cout = k; op.Ctot = 3;
           op.w_off = Lp.w_off; op.b_off = Lp.b_off;
           op.out = tmp; op.NB = N2; op.H = HL(lv); op.W = WL(lv);
-          op.tile = (k % 64 == 0 ? TILE_256x64 : TILE_256x32) | CONV_TILE_XCD | CONV_TILE_C3;
+          op.tile = ((k == 64 || k == 32) ? TILE_C3_DIRECT : k % 64 == 0 ? TILE_256x64 : TILE_256x32) | CONV_TILE_XCD | CONV_TILE_C3;
           op.flops = 2.0 * N2 * HL(lv) * WL(lv) * k * 27; op.bytes = 4.0 * N2 * HL(lv) * WL(lv) * (3 + k);
           P->ops.push_back(op);
         } else {
@@ -1051,11 +1051,15 @@ int autotune_plan(film_t* h, Plan* P) {
       float best_ms = 1e30f;
       std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
+        // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
+        // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
         cands.clear();
-        for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
-          cands.push_back(sh | CONV_TILE_C3);
-          cands.push_back(sh | CONV_TILE_C3 | CONV_TILE_XCD);
-        }
+        if (op.Cout == 64 || op.Cout == 32) cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
+        else
+          for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
+            cands.push_back(sh | CONV_TILE_C3);
+            cands.push_back(sh | CONV_TILE_C3 | CONV_TILE_XCD);
+          }
       }
       for (int tile : cands) {
         OpDesc trial = op;
@@ -1255,7 +1259,7 @@ uint32_t film_crc32c(uint32_t crc, const void* data, int64_t n) {
   return ~c;
 }
 
-const char* film_version(void) { return "gfx950;film_hip r1"; }
+const char* film_version(void) { return "gfx950;film_hip r2"; }
 
 int film_default_config(film_config* cfg) {
   if (!cfg) return FILM_ERR_INVALID;

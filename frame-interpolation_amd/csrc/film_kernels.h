@@ -176,7 +176,8 @@ struct TileMapParams {
 
 // Tile id = shape index + CONV_TILE_XCD when the XCD-contiguous block mapping is used.
 enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 = 3, TILE_128x32 = 4,
-                TILE_128x64 = 5, TILE_256x128 = 6 /* 8 waves, 4x2 */, TILE_SHAPES = 7, CONV_TILE_XCD = 16,
+                TILE_128x64 = 5, TILE_256x128 = 6 /* 8 waves, 4x2 */, TILE_SHAPES = 7,
+                TILE_C3_DIRECT = 7 /* with CONV_TILE_C3: conv_c3_kernel (no LDS, weights in registers, conv_c3_impl.h) */, CONV_TILE_XCD = 16,
                 CONV_TILE_C3 = 32 /* first-layer mode: 3-channel image input, [48][Cout] weights */,
                 CONV_TILE_HALO = 64 /* conv_halo_kernel: shape index = HaloTile, weights [Cout][chunk][tap][16] */,
                 CONV_TILE_WINO = 256 /* conv_wino_kernel (F(2,3) along x): shape index = WinoTile, weights

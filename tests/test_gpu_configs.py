@@ -209,3 +209,37 @@ def test_eval_cli_on_vimeo_sized_triplets(published, tmp_path):
         print(r[0], 'hip', got, 'oracle', want)
         assert np.allclose(got[:3], want[:3], rtol=0, atol=2e-6) and abs(got[3] - want[3]) < 2e-3   # dB
     assert sorted(os.listdir(out))[:4] == ['00001_0001_image.png', '00001_0001_x0.png', '00001_0001_x1.png', '00001_0001_y.png']
+
+
+def test_rccl_broadcast_path_single_rank(published):
+    """The device side of the N-GPU start-up on the hardware that is available (one GPU): torch.distributed with the
+    nccl (= RCCL) backend and world_size 1, film_hip.sharding.broadcast_weights with a CUDA blob (film_export_packed to
+    device memory, dist.broadcast on it), then film_import_packed from that device blob into a second engine, whose
+    result must be bit-identical.  (N > 1 is covered on CPU with gloo: tests/test_dist_cpu.py.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from film_hip.engine import FilmEngine
+    from film_hip.sharding import broadcast_weights
+    opt, w, eng = published
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        broadcast_weights(eng, dist, src=0, device=dev)
+        n = eng.packed_size()
+        blob = torch.empty(n, dtype=torch.float32, device=dev)
+        eng.export_packed_device(blob.data_ptr(), n)
+        dist.broadcast(blob, src=0)
+        torch.cuda.synchronize(dev)
+        e2 = FilmEngine(opt, device=0)
+        e2.import_packed_device(blob.data_ptr(), n)
+        assert float(blob.abs().sum()) > 0 and np.array_equal(e2.export_packed(), eng.export_packed())
+        x0, x1 = TI.frame_pair(1, 128, 192, seed=8)
+        assert np.array_equal(e2.forward(x0, x1), eng.forward(x0, x1))
+        e2.close()
+    finally:
+        dist.destroy_process_group()
