@@ -54,9 +54,9 @@ def main():
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         print(f'| `{k}` | {a[0] / args.forwards:.1f} | {a[1] / args.forwards / 1e3:.3f} | {a[1] / a[0]:.1f} | {a[2]:.1f} | '
               f'{a[3]:.1f} | {100 * a[1] / total:.2f} |')
-    conv = sum(a[1] for k, a in agg.items() if k.startswith(('conv_buf', 'conv_halo', 'conv_wino', 'conv_fold', 'conv_igemm')))
-    nconv = sum(a[0] for k, a in agg.items() if k.startswith(('conv_buf', 'conv_halo', 'conv_wino', 'conv_fold', 'conv_igemm')))
-    print(f'\nMFMA conv kernels (conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf, all tile shapes, + the first-layer conv_igemm_kernel): {nconv / args.forwards:.0f} launches/forward, '
+    conv = sum(a[1] for k, a in agg.items() if k.startswith(('conv_buf', 'conv_halo', 'conv_wino', 'conv_fold', 'conv_igemm', 'conv_c3')))
+    nconv = sum(a[0] for k, a in agg.items() if k.startswith(('conv_buf', 'conv_halo', 'conv_wino', 'conv_fold', 'conv_igemm', 'conv_c3')))
+    print(f'\nMFMA conv kernels (conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf, all tile shapes, + the first-layer conv_c3_kernel / conv_igemm_kernel): {nconv / args.forwards:.0f} launches/forward, '
           f'{conv / args.forwards / 1e3:.3f} ms/forward, average launch {conv / nconv:.1f} us')
 
 
