@@ -387,6 +387,15 @@ def test_4k_frame_crosses_the_4gib_buffer_rule(published):
     b = eng.interpolate_frames(x0, x1, align=64, block_shape=[4, 4])
     eng.set_option('max_batch', 0)
     assert np.array_equal(a, b)
+    # two of the sixteen tiles against the oracle (each tile is an independent 960x540 patch padded to 960x576)
+    from oracle import film_oracle as fo
+    orc = fo.OracleInterpolator(w, align=64)
+    for ty, tx in ((0, 3), (2, 1)):
+        ys, xs = slice(ty * 540, (ty + 1) * 540), slice(tx * 960, (tx + 1) * 960)
+        want = orc.interpolate(x0[:, ys, xs], x1[:, ys, xs], None)
+        d = float(np.abs(a[:, ys, xs] - want).max())
+        print(f'4K tile ({ty},{tx}): hip vs oracle max|d| {d:.3e}')
+        assert d < IMAGE_TOL
 
 
 def test_errors(published):
