@@ -115,6 +115,7 @@ static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
     case W43_Q16_4x64_T12_P2: return conv_wino43_launch<4, 64, 1, 2, F | W43_F_PF2, 16>(p, s);
     case W43_Q16_4x32_T11_P2: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_PF2, 16>(p, s);
     case W43_Q16_4x64_N1_P2: return conv_wino43_launch<4, 64, 1, 1, F | W43_F_PF2, 16, 1>(p, s);
+    case W43_Q16_4x32_T11_BG: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_BG, 16>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -39,10 +39,13 @@ enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priori
        W43_DBG_NOFRAG = 2048,
        W43_DBG_NOALOAD = 4096, // activation loads skipped, transform + LDS stores of stale registers kept
        W43_DBG_NOASTORE = 8192,// activation loads kept, transform + LDS stores skipped
-       W43_F_PF2 = 32768 };    // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
+       W43_F_PF2 = 32768,      // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
+       W43_F_BG = 65536 };     // weight fragments straight from global memory (L1 / L2) into registers, requested two stages
+                               // ahead: no weight ring in LDS (36 KB instead of 54 KB for the 32-channel tile = FOUR workgroups
+                               // per CU), no weight stores, two barriers per chunk instead of three
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
-__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU
+__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & 65536) != 0 && BN == 32 && QW == 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
   constexpr int RPT = 32 / QW;                 // patch rows per 32-quad MFMA tile
   constexpr int MT = TH / RPT;                 // MFMA row tiles per patch; TM of them per wave
   constexpr int NU = 6 / NH;                   // nu planes per wave
@@ -59,7 +62,8 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   constexpr int PXW = 4 * QW;                  // patch width in pixels
   static_assert(QW == 32 || QW == 16, "quads per patch row");
   static_assert(TH % RPT == 0 && MT % TM == 0 && BN % (32 * TN) == 0 && ITEMS <= NT && 2 * ITEMS > NT, "bad tile");
-  static_assert(NH == 1 || 2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + 3 * B_STAGE, "exchange buffer does not fit");
+  constexpr bool BG = (FLAGS & W43_F_BG) != 0;
+  static_assert(NH == 1 || 2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + (BG ? 0 : 3 * B_STAGE), "exchange buffer does not fit");
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
   extern __shared__ __attribute__((aligned(1024))) float smem[];  // [A0][A1][B ring x3]
@@ -137,7 +141,22 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
 
   constexpr bool PF2 = (FLAGS & W43_F_PF2) != 0;
   bf4 araw[PF2 ? 2 : 1][6];   // PF2: chunk parity -> register set
-  bf4 breg[3][BLD];   // weights in flight: requested in stage s for stage s+3, written to the ring in stage s+1
+  bf4 breg[BG ? 1 : 3][BLD];   // weights in flight: requested in stage s for stage s+3, written to the ring in stage s+1
+  // BG: the B fragments of this wave, [stage mod 3][nu step][channel tile]: lane (cout = l31, K half) reads the 16 bytes
+  // [cout][stage][nu][4 half .. 4 half + 3] of the weight image, requested in stage s - 2
+  bf4 fbg[BG ? 3 : 1][BG ? NU : 1][TN];
+  unsigned bgoff[TN];
+#pragma unroll
+  for (int nt = 0; nt < TN; ++nt)
+    bgoff[nt] = (unsigned)((size_t)(n0 + (ng * TN + nt) * 32 + l31) * nstage * 192 + (NU * h) * 32 + half * 16);
+  auto load_bg = [&](int s, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    const unsigned so = (unsigned)(s < nstage ? s : nstage - 1) * 192u;
+#pragma unroll
+    for (int j = 0; j < (BG ? NU : 1); ++j)
+#pragma unroll
+      for (int nt = 0; nt < TN; ++nt) fbg[BG ? SET : 0][j][nt] = conv_buf_load(brsrc, bgoff[nt] + (unsigned)j * 32u, so);
+  };
   bool chunk_ok = true;
   auto load_item = [&](auto set_c) {
     constexpr int SET = decltype(set_c)::value;
@@ -211,11 +230,13 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     if constexpr ((FLAGS & W43_DBG_NOFRAG) != 0) { if (in_loop) return; }
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) fa[J % 3][mt] = smem4[a_base + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
+    if constexpr (!BG) {
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) fb[J % 3][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
+      for (int nt = 0; nt < TN; ++nt) fb[J % 3][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
+    }
   };
-  auto compute = [&](auto j_c) {
-    constexpr int J = decltype(j_c)::value;
+  auto compute = [&](auto dy_c, auto j_c) {
+    constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
     if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
-          acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J % 3][mt][k], fb[J % 3][nt][k], acc[mt][J][nt], 0, 0, 0);
+          acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J % 3][mt][k], BG ? fbg[BG ? DY : 0][BG ? J : 0][nt][k] : fb[J % 3][nt][k], acc[mt][J][nt], 0, 0, 0);
     if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(0);
   };
 
@@ -237,13 +258,20 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   setup_seg();
   const int sb = kbeg * 3;
   load_item(C0{});    // every request of the prologue first, then the stores: one load latency instead of three
-  load_b(sb + 0, 0);
-  load_b(sb + 1, 1);
-  load_b(sb + 2, 2);
+  if constexpr (BG) {
+    load_bg(sb + 0, C0{});
+    load_bg(sb + 1, C1{});
+  } else {
+    load_b(sb + 0, 0);
+    load_b(sb + 1, 1);
+    load_b(sb + 2, 2);
+  }
   if constexpr (PF2) { next_chunk(kbeg + 1); load_item(C1{}); }   // chunk 1 stays in registers until chunk 0's dy = 1 stage
   store_item(0, C0{});
-  store_b(0, 0);
-  store_b(1, 1);
+  if constexpr (!BG) {
+    store_b(0, 0);
+    store_b(1, 1);
+  }
   next_chunk(kbeg + (PF2 ? 2 : 1));
   __syncthreads();
   fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur);
@@ -260,26 +288,30 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     const int a_next = a_ad + (a_stage ^ 1) * A_STAGE4;
     auto stage = [&](auto dy_c) {
       constexpr int DY = decltype(dy_c)::value;
-      if constexpr ((FLAGS & W43_DBG_NOB) == 0) load_b(s0 + DY + 3, DY);
+      if constexpr (BG) load_bg(s0 + DY + 2, std::integral_constant<int, (DY + 2) % 3>{});
+      else if constexpr ((FLAGS & W43_DBG_NOB) == 0) load_b(s0 + DY + 3, DY);
       if constexpr (DY == 0 && (FLAGS & (W43_DBG_NOA | W43_DBG_NOALOAD)) == 0) load_item(std::integral_constant<int, PF2 ? PAR : 0>{});
       fetch(dy_c, std::integral_constant<int, 1>{}, a_cur);
-      compute(std::integral_constant<int, 0>{});
+      compute(dy_c, std::integral_constant<int, 0>{});
       fetch(dy_c, std::integral_constant<int, 2>{}, a_cur);
-      compute(std::integral_constant<int, 1>{});
+      compute(dy_c, std::integral_constant<int, 1>{});
       if constexpr (NU == 6) {
         fetch(dy_c, std::integral_constant<int, 3>{}, a_cur);
-        compute(std::integral_constant<int, 2>{});
+        compute(dy_c, std::integral_constant<int, 2>{});
         fetch(dy_c, std::integral_constant<int, 4>{}, a_cur);
-        compute(std::integral_constant<int, 3>{});
+        compute(dy_c, std::integral_constant<int, 3>{});
         fetch(dy_c, std::integral_constant<int, 5>{}, a_cur);
-        compute(std::integral_constant<int, 4>{});
+        compute(dy_c, std::integral_constant<int, 4>{});
       }
       fetch(std::integral_constant<int, (DY + 1) % 3>{}, std::integral_constant<int, 0>{}, DY == 2 ? a_next : a_cur);
-      compute(std::integral_constant<int, NU - 1>{});
+      compute(dy_c, std::integral_constant<int, NU - 1>{});
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr ((FLAGS & W43_DBG_NOB) == 0) store_b((DY + 2) % 3, (DY + 2) % 3);
+      if constexpr (!BG && (FLAGS & W43_DBG_NOB) == 0) store_b((DY + 2) % 3, (DY + 2) % 3);
       if constexpr (DY == 1 && (FLAGS & (W43_DBG_NOA | W43_DBG_NOASTORE)) == 0) store_item(a_stage ^ 1, std::integral_constant<int, PF2 ? 1 - PAR : 0>{});
-      if constexpr ((FLAGS & W43_DBG_NOBAR) == 0) __syncthreads();
+      // BG: only the activation double buffer is shared.  It is written in the dy = 1 stage: the barrier of dy = 0 puts every
+      // wave's reads of the previous chunk in front of that write, the barrier of dy = 1 puts the write in front of the
+      // first read (the fragment prefetch at the end of dy = 2)
+      if constexpr ((FLAGS & W43_DBG_NOBAR) == 0 && (!BG || DY != 2)) __syncthreads();
     };
     stage(std::integral_constant<int, 0>{});
     stage(std::integral_constant<int, 1>{});
@@ -296,6 +328,8 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   } else {
     for (int kc = kbeg; kc < kend; ++kc) chunk(kc, C0{});
   }
+
+  if constexpr (BG && NH == 2) __syncthreads();   // no barrier behind the last dy = 2 stage: the exchange below reuses the activation buffers
 
   // ---- epilogue: y0 = (m0+m1+m2) + (m3+m4), y1 = (m1-m2) + 2(m3-m4) on half 0; y2 = (m1+m2) + 4(m3+m4),
   // y3 = (m1-m2) + (8(m3-m4) + m5) on half 1.  The halves swap the bracketed sums they lack through LDS (the staging
@@ -440,7 +474,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
 hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = (2 * (size_t)(TH + 2) * 6 * QW * 8 + 3 * 6 * (size_t)BN * 8) * sizeof(float);
+  constexpr size_t lds = (2 * (size_t)(TH + 2) * 6 * QW * 8 + ((FLAGS & W43_F_BG) != 0 ? 0 : 3 * 6 * (size_t)BN * 8)) * sizeof(float);
   constexpr int NT = ((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH;
   static_assert(lds <= 160 * 1024, "LDS");
   auto kern = conv_wino43_kernel<TH, BN, TM, TN, FLAGS, QW, NH>;

@@ -488,7 +488,7 @@ struct Planner {
     if (op.wino == 1 && h->opt_wino != 2 && L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W)) op.wino = 3;
     if (op.split || op.wino) op.halo = 0;
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
-    op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_P2) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
+    op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_BG) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
               : op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
@@ -979,8 +979,8 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false) {
   // the 64-pixel ("Q16", two workgroups per CU) tiles won every layer of the 1080p plan against the 128-pixel ones
   // (profiles/r02_conv_bench_w43.log); one 128-pixel tile stays in the list for shapes nobody measured
   std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11, W43_Q16_4x64_N1,
-                                                              W43_Q16_4x64_T21_P2, W43_Q16_4x64_T12_P2, W43_Q16_4x32_T11_P2, W43_Q16_4x64_N1_P2}
-                                            : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11, W43_Q16_4x32_T11_P2};
+                                                              W43_Q16_4x64_T21_P2, W43_Q16_4x64_T12_P2, W43_Q16_4x32_T11_P2, W43_Q16_4x64_N1_P2, W43_Q16_4x32_T11_BG}
+                                            : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11, W43_Q16_4x32_T11_P2, W43_Q16_4x32_T11_BG};
   std::vector<int> out;
   for (int sh : shapes) {
     if (pool && (sh == W43_4x64_T21 || sh == W43_4x64_T12 || sh == W43_4x32_T11)) continue;   // the fused pool needs a 64-pixel tile

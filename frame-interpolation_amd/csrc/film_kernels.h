@@ -197,7 +197,10 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
 enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_4x64_T21 = 3, W43_Q16_4x64_T12 = 4, W43_Q16_4x32_T11 = 5,
                   W43_Q16_4x64_N1 = 6 /* a wave owns all six nu planes of one 32x32 tile: no epilogue exchange */,
                   /* the Q16 tiles with the activation loads requested two K chunks ahead (second register set) */
-                  W43_Q16_4x64_T21_P2 = 7, W43_Q16_4x64_T12_P2 = 8, W43_Q16_4x32_T11_P2 = 9, W43_Q16_4x64_N1_P2 = 10 };
+                  W43_Q16_4x64_T21_P2 = 7, W43_Q16_4x64_T12_P2 = 8, W43_Q16_4x32_T11_P2 = 9, W43_Q16_4x64_N1_P2 = 10,
+                  /* the 32-channel Q16 tile with the weight fragments read straight from global memory (no weight ring: 36 KB of
+                     LDS, <= 128 VGPRs -> FOUR workgroups per CU; the short K loops of the 32-channel layers are latency bound) */
+                  W43_Q16_4x32_T11_BG = 11 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

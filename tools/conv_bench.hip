@@ -71,6 +71,7 @@ static Variant variants[] = {
     F43Q(4, 64, 2, 1, 4), F43Q(4, 64, 1, 2, 4), F43Q(4, 32, 1, 1, 4), F43Q(4, 64, 2, 1, 0),
     F43N(4, 64, 4), F43N(4, 64, 0),
     F43Q(4, 64, 2, 1, 260), F43Q(4, 64, 2, 1, 3844), F43N(4, 64, 32772), F43N(4, 64, 32768), F43Q(4, 64, 1, 2, 32772), F43Q(4, 64, 2, 1, 32772), F43Q(4, 32, 1, 1, 32772),
+    F43Q(4, 32, 1, 1, 65540), F43N(4, 64, 65540), F43Q(4, 64, 2, 1, 65540),
     X(4, 128, 2, 2), XA(4, 128, 2, 2, 1028), XA(4, 128, 2, 2, 2052), XA(4, 64, 2, 1, 1028), XA(4, 64, 2, 1, 2052), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
     S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 128, 2, 2, 3), S(16, 128, 4, 2, 3), S(16, 64, 4, 1, 3), S(8, 64, 2, 1, 3), S(16, 128, 4, 1, 3), S(8, 64, 4, 1, 3), S(4, 128, 2, 2, 3), S(8, 32, 4, 1, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
@@ -191,6 +192,8 @@ static Shape shapes[] = {
     {"flow_l1_c0  M=1.1M   C=384->64 3x3", 8, 288, 480, 384, 64, 3},
     {"fusion_3_1  M=34560  C=2448->512 3x3", 4, 72, 120, 2448, 512, 3},
     {"flow_l3_c0  M=69120  C=1920->256 3x3", 8, 72, 120, 1920, 256, 3},
+    {"flow_l0_c1  M=4.4M   C=32->32 3x3", 8, 576, 960, 32, 32, 3},
+    {"flow_l1_c1  M=1.1M   C=64->64 3x3", 8, 288, 480, 64, 64, 3},
 };
 
 int main(int argc, char** argv) {
