@@ -18,6 +18,7 @@
 #include <thread>
 #include <cmath>
 #include <cstdarg>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -471,9 +472,15 @@ struct Planner {
     op.split = (h->opt_precision != 0 && L.has_halo() && !any_up && (px >= 2048 || h->opt_halo_all)) ? h->opt_precision : 0;
     // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M.
     // In precision mode bf16x3 the same layers run the Winograd form of the split kernel (conv_winox3_kernel).
+    // F(4,3) needs the level width to fill its 64-pixel patches (at most 15 % of the last patch of a row empty)
+    const bool w43_width = L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W);
+    // deep K on a small level (the 36x60 level of a 1080p tile, K = 1920): only with F(4,3) AND its split-K, which cuts the
+    // few long workgroups of such a layer into enough pieces to fill the chip
+    const bool deep_small = L.cout % 128 == 0 && px >= 2048 && px < 8192 && ctot > 1024 && w43_width && h->opt_splitk &&
+                            h->opt_wino == 1 && h->opt_precision == 0;
     op.wino = op.split != 1 && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
               ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
-               px >= 100000 || h->opt_wino >= 2);
+               px >= 100000 || h->opt_wino >= 2 || deep_small);
     if (op.wino && h->opt_precision == 2 && (op.split == 2 || h->opt_wino >= 2)) {
       // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  The Winograd form wins with the 2 x 2 wave block of
       // its 128-channel tile (0.88-0.94x the time of conv_halo_split_kernel<..,3> per layer, 427 vs 367 TFLOP/s at
@@ -485,7 +492,7 @@ struct Planner {
     // fp32: F(4,3) along x (conv_wino43_kernel, 2x fewer MFMAs than direct where F(2,3) has 1.5x) on the levels whose width
     // fills its 64-pixel patches (the Q16 tiles; at most 15 % of the last patch of a row empty: 960 ... 60, 448, 256 ...); wino = 3.  "winograd" = 2 / 3 force
     // F(2,3) / F(4,3) onto every eligible layer (tests).
-    if (op.wino == 1 && h->opt_wino != 2 && L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W)) op.wino = 3;
+    if (op.wino == 1 && h->opt_wino != 2 && w43_width) op.wino = 3;
     if (op.split || op.wino) op.halo = 0;
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
     op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_BG) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
@@ -513,9 +520,15 @@ struct Planner {
     // the CUs for the full duration of a deep K loop.  Two K ranges double the workgroup count at half the length; the partial sums are added in split order by conv_splitk_reduce_kernel.  Factor from
     // the level size and the layer only.
     if (h->opt_splitk && op.wino == 3 && L.cout % 4 == 0) {
-      // measured (profiles/r02_per_op_profile.json vs the run before): -10 % on the K = 2448 / 1920 layers of the 120-wide
-      // level, +7..10 % on its K <= 512 layers (reduce kernel + twice the prologues / epilogues) -> deep K only
-      int S = (ctot >= 1024 && px <= 16384) ? 2 : 1;
+      // 72x120 level, measured (profiles/r02_per_op_profile.json vs the run before): -10 % on the K = 2448 / 1920 layers,
+      // +7..10 % on its K <= 512 layers (reduce kernel + twice the prologues / epilogues) -> deep K only
+      // small levels (<= 4096 pixels per image: the 36x60 level of a 1080p tile, the 64x64 level of a 256x256 frame) have
+      // 9-16 patches per image and channel block: K ranges of >= 128 channels, up to 8 of them (A/B on the GPU: 36x60 level
+      // 2.90 -> 2.31 ms per 1080p step incl. its K = 1920 layer moving here from conv_buf_kernel; 64x64 level of a 256x256
+      // pair 1.05 -> 0.86 ms; K < 512 left alone - the split would also undo the fused pooling of those layers)
+      int S = 1;
+      if (px <= 4096 && ctot >= 512) S = std::min(8, ctot / 128);
+      else if (px <= 16384 && ctot >= 1024) S = 2;
       if (S > 1) {
         op.ksplit = S;
         const int sb = add_scratch("splitk:" + op.tag, (int64_t)S * M * L.cout);
