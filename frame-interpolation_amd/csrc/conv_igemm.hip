@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 
 static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = tile & (CONV_TILE_XCD - 1);
-  if (p.pool_out != nullptr && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
+  if ((p.pool_out != nullptr || p.pw_out != nullptr) && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
   if (tile & CONV_TILE_FOLDX3) {
     if (p.ksize != 2 || p.fold != 2) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_foldx3<CONV_B_XCD_M>(p, shape, s) : launch_foldx3<0>(p, shape, s);
@@ -177,6 +177,9 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
     if (p.ksize != 3) return hipErrorInvalidValue;
     if (tile & CONV_TILE_X3) return (tile & CONV_TILE_XCD) ? launch_winox3<CONV_B_XCD_M>(p, shape, s) : launch_winox3<0>(p, shape, s);
     if ((tile & CONV_TILE_F43) && p.pool_out != nullptr && shape < W43_Q16_4x64_T21) return hipErrorInvalidValue;   // fused pool: 64-pixel tiles only
+    if (p.pw_out != nullptr && (!(tile & CONV_TILE_F43) || (shape != W43_Q16_4x64_N1 && shape != W43_Q16_4x64_N1_P2) || p.Cout != 64 || p.ksplit > 1 ||
+                                p.pool_out != nullptr || p.pw_cout < 1 || p.pw_cout > 4))
+      return hipErrorInvalidValue;   // fused 1x1: a workgroup must hold all 64 channels of its pixels in one wave set
     if (tile & CONV_TILE_F43) return (tile & CONV_TILE_XCD) ? launch_wino43<CONV_B_XCD_M>(p, shape, s) : launch_wino43<0>(p, shape, s);
     return (tile & CONV_TILE_XCD) ? launch_wino<CONV_B_XCD_M>(p, shape, s) : launch_wino<0>(p, shape, s);
   }

@@ -447,7 +447,50 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
           if (x + j < p.W) p.out[(rowbase + x + j) * p.ostride + n] = o[j];
       }
     };
-    if (QW == 16 && p.pool_out != nullptr && ksp == 1) {
+    if (QW == 16 && BN == 64 && p.pw_out != nullptr) {
+      // fused 1x1 convolution: the activated tile goes to LDS as [pixel = patch row * 64 + x][65] (the K loop ended with a
+      // barrier: the staging buffers are free), then thread = pixel sums its 64 channels
+      static_assert(NH != 1 || QW != 16 || BN != 64 || (size_t)TH * 64 * 65 <= 2 * A_STAGE + 3 * B_STAGE, "1x1 tile does not fit");
+      float* const tile = smem;
+      if constexpr (BG) __syncthreads();   // (no barrier behind the last stage of the K loop)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m0 = acc[0][0][0][r], m1 = acc[0][1][0][r], m2 = acc[0][2][0][r], m3 = acc[0][3][0][r], m4 = acc[0][4][0][r],
+                    m5 = acc[0][5][0][r];
+        float o[4];
+        o[0] = ((m0 + m1) + m2) + (m3 + m4);
+        o[1] = (m1 - m2) + 2.f * (m3 - m4);
+        o[2] = (m1 + m2) + 4.f * (m3 + m4);
+        o[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
+        const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int pxl = (wm * RPT + mrow / QW) * 64 + 4 * (mrow % QW);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v = o[j] + bv;
+          if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+          tile[(pxl + j) * 65 + ng * 32 + l31] = v;
+        }
+      }
+      __syncthreads();
+      if (t < TH * 64) {
+        const int y = y0 + t / 64, x = x0 + (t & 63);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* row = tile + t * 65;
+#pragma unroll 8
+        for (int c = 0; c < 64; ++c) {
+          const float v = row[c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < p.pw_cout) a[j] = __builtin_fmaf(v, p.pw_w[c * p.pw_cout + j], a[j]);
+        }
+        if (y < p.H && x < p.W) {
+          float* d = p.pw_out + (((size_t)img * p.H + y) * p.W + x) * p.pw_ostride;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < p.pw_cout) d[j] = a[j] + p.pw_bias[j];
+        }
+      }
+    } else if (QW == 16 && p.pool_out != nullptr && ksp == 1) {
       const int yp = (y0 >> 1) + wm;
 #pragma unroll
       for (int r = 0; r < 8; ++r) {      // rows 2k (r) and 2k + 1 (r + 8) of the same quad

@@ -89,6 +89,7 @@ struct OpDesc {
   View in, in2, out;
   View pack_b, pack_f, pack_out;   // warp: fused pack_flow (0.5 * flows into the aligned pyramid)
   View img_in, img_out;   // warp: fused 3-channel image warp with the same flow (t = 0.5 stage)
+  View pw_out; int pw_cout = 0;   // conv: fused 1x1 convolution behind it (weights w2_off / b2_off) writes pw_out; `out` is not written then
   View in3, out2;   // warp: coarser flow to upsample / the upsampled flow it stores; flow heads: in2 = upsampled flow, out2 = v = out + in2
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
   float fscale = 1.f;
@@ -171,7 +172,7 @@ struct film_handle {
   int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
-  int opt_fuse = 15;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
+  int opt_fuse = 31;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
@@ -812,7 +813,24 @@ struct Planner {
       conv(tg, base + "_2", {s2}, view(fu_b[i], 0, 0, ff[i]), B, HL(i), WL(i), true);
       net = view(fu_b[i], 0, 0, ff[i]);
     }
-    conv_pw("fusion_out", "fusion/output_conv", net, view(out, 0, 0, 3), (int64_t)B * H * W, false);
+    {
+      // RGB head (fusion.py:138-140): a 1x1 convolution of the last decoder layer.  Fused (option fuse bit 16) into that
+      // layer's epilogue when it runs on conv_wino43_kernel with 64 output channels and no split: the 64-channel
+      // activation (566 MB per 1080p step) is then neither written nor read back.
+      OpDesc& last = P->ops.back();
+      const LayerPack& LO = h->layers[h->layer_idx.at("fusion/output_conv")];
+      if ((h->opt_fuse & 16) && last.kind == OP_CONV && last.wino == 3 && last.Cout == 64 && last.ksplit <= 1 && last.out2.buf < 0 &&
+          LO.cout <= 4 && LO.cin == 64) {
+        last.tag += "+output_conv";
+        last.pw_out = view(out, 0, 0, 3); last.pw_cout = LO.cout;
+        last.w2_off = LO.w_off; last.b2_off = LO.b_off;
+        last.tile = W43_Q16_4x64_N1_P2 | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD;
+        last.flops += 2.0 * (double)B * H * W * LO.cout * LO.cin;
+        last.bytes = 4.0 * (double)B * H * W * (64 + LO.cout);
+      } else {
+        conv_pw("fusion_out", "fusion/output_conv", net, view(out, 0, 0, 3), (int64_t)B * H * W, false);
+      }
+    }
     if (bad) return fail(h, FILM_ERR_INVALID, "%s", bad_msg.c_str());
     P->arena_floats = cursor;   // the split-K partial-sum regions are added while the ops are emitted
     analyze_lanes();
@@ -835,7 +853,8 @@ struct Planner {
     if (op.in3.buf >= 0) rd.push_back(access(op.in3));
     if (op.img_in.buf >= 0) rd.push_back(access(op.img_in));
     if (op.pack_b.buf >= 0) { rd.push_back(access(op.pack_b)); rd.push_back(access(op.pack_f)); }
-    if (op.out.buf >= 0) wr.push_back(access(op.out));
+    if (op.out.buf >= 0 && op.pw_out.buf < 0) wr.push_back(access(op.out));
+    if (op.pw_out.buf >= 0) wr.push_back(access(op.pw_out));
     if (op.out2.buf >= 0) wr.push_back(access(op.out2));
     if (op.img_out.buf >= 0) wr.push_back(access(op.img_out));
     if (op.pack_out.buf >= 0) wr.push_back(access(op.pack_out));
@@ -892,6 +911,9 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.fold = op.fold; p.py = op.py; p.px = op.px; p.ftaps = op.ftaps;
       p.ksplit = op.ksplit; p.part = op.ksplit > 1 ? arena + op.part_off : nullptr;
       if (op.out2.buf >= 0) { p.pool_out = mptr(arena, op.out2); p.pool_ostride = op.out2.stride; }
+      if (op.pw_out.buf >= 0) {
+        p.pw_w = wts + op.w2_off; p.pw_bias = wts + op.b2_off; p.pw_out = mptr(arena, op.pw_out); p.pw_ostride = op.pw_out.stride; p.pw_cout = op.pw_cout;
+      }
       for (int q = 0; q < 4; ++q) { p.tdy[q] = (signed char)op.tdy[q]; p.tdx[q] = (signed char)op.tdx[q]; p.fold_woff[q] = op.fold_woff[q]; }
       return film_launch_conv(p, op.tile, s);
     }
@@ -988,7 +1010,12 @@ std::vector<int> wino_candidates(int Cout) {
   return out;
 }
 
-std::vector<int> wino43_candidates(int Cout, bool pool = false) {
+std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false) {
+  if (pw) {   // the fused 1x1 needs every channel of a pixel in one workgroup: the NH = 1 tiles at Cout = 64
+    std::vector<int> out;
+    for (int sh : {W43_Q16_4x64_N1, W43_Q16_4x64_N1_P2}) { out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43); out.push_back(sh | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD); }
+    return out;
+  }
   // the 64-pixel ("Q16", two workgroups per CU) tiles won every layer of the 1080p plan against the 128-pixel ones
   // (profiles/r02_conv_bench_w43.log); one 128-pixel tile stays in the list for shapes nobody measured
   std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W43_4x64_T21, W43_Q16_4x64_T21, W43_Q16_4x64_T12, W43_Q16_4x32_T11, W43_Q16_4x64_N1,
@@ -1036,7 +1063,7 @@ std::vector<int> tile_candidates(int Cout) {
 
 std::string conv_signature(const OpDesc& op) {
   std::ostringstream o;
-  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << ':' << op.ksplit << ':' << (op.out2.buf >= 0);
+  o << op.NB << 'x' << op.H << 'x' << op.W << ':' << op.Cout << ':' << op.ksize << ':' << op.out.stride << ':' << op.c3 << ':' << op.halo << ':' << op.split << ':' << op.wino << ':' << op.fold << ':' << op.ksplit << ':' << (op.out2.buf >= 0) << ':' << op.pw_cout;
   for (int i = 0; i < op.nseg; ++i)
     o << '|' << op.seg[i].v.C << ',' << op.seg[i].v.stride << ',' << op.seg[i].up << ',' << op.seg[i].bmod;
   return o.str();
@@ -1062,7 +1089,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
       if (op.c3) {
         // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
         // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
@@ -1207,6 +1234,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     json_view(o, "in2", op.in2, P); o << ",";
     json_view(o, "in3", op.in3, P); o << ",";
     json_view(o, "out2", op.out2, P); o << ",";
+    json_view(o, "pw_out", op.pw_out, P); o << ",\"pw_cout\":" << op.pw_cout << ",";
     json_view(o, "img_in", op.img_in, P); o << ",";
     json_view(o, "img_out", op.img_out, P); o << ",";
     json_view(o, "pack_b", op.pack_b, P); o << ",";
@@ -1657,12 +1685,12 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     if (h->finalized) { int rc = film_ensure_groups_(h, (int)value); if (rc) return rc; }
   }
   else if (!strcmp(key, "fuse")) {
-    if ((int)(value & 15) != h->opt_fuse) {  // plans carry the op list: drop them
+    if ((int)(value & 31) != h->opt_fuse) {  // plans carry the op list: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
       h->plans.clear();
       h->last_plan = nullptr;
-      h->opt_fuse = (int)(value & 15);
+      h->opt_fuse = (int)(value & 31);
     }
   }
   else if (!strcmp(key, "fold2x2")) {

@@ -61,6 +61,13 @@ struct ConvParams {
   // the activated outputs it holds in registers - the former pool launch and its re-read of the feature map.  H, W even.
   float* pool_out;    // nullptr: none
   int pool_ostride;
+  // Fused 1x1 convolution behind this layer (conv_wino43_kernel, the NH = 1 tiles with BN = Cout = 64: a workgroup holds every
+  // channel of its 256 pixels): pw_out[pixel][j] = sum_c act(out[pixel][c]) * pw_w[c][j] + pw_bias[j], one fma chain per output
+  // in channel order like conv_pw_kernel; `out` itself is NOT written.  The RGB head of the fusion decoder (fusion.py:138-140).
+  const float* pw_w;      // [Cout][pw_cout]; nullptr: none
+  const float* pw_bias;
+  float* pw_out;
+  int pw_ostride, pw_cout;   // pw_cout <= 4
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,

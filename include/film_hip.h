@@ -148,11 +148,13 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  latency of small frames.  Changing it drops the cached plans.
  *   "pack_groups" n  pack (and upload) the weight layout groups 1..n now: 1 default fp32 layouts, 2 + F(2,3) copy, 3 + halo
  *                  copy, 4 + bf16 split copies (normally packed on demand)
- *   "fuse"    bits 15 (default): small-launch fusion, identical arithmetic and bit-identical results.  1: tf.image.resize(2 * v)
+ *   "fuse"    bits 31 (default): small-launch fusion, identical arithmetic and bit-identical results.  1: tf.image.resize(2 * v)
  *                  of the flow estimator inside the warp kernels that consume it; 2: v = residual + upsampled flow inside
  *                  the flow-head kernels; 4: the 3-channel image warps of the t = 0.5 stage inside the feature warps of the
  *                  same flow; 8: AveragePooling2D of the sub-extractor
- *                  stages in the epilogue of the F(4,3) convolution in front of it (about 35 launches fewer per forward in all).  0: one launch per reference op.  Drops the cached plans.
+ *                  stages in the epilogue of the F(4,3) convolution in front of it (about 35 launches fewer per forward in all);
+ *                  16: the RGB head (1x1 convolution, fusion.py:138-140) in the epilogue of the last decoder layer, whose
+ *                  64-channel output is then never written.  0: one launch per reference op.  Drops the cached plans.
  *   "fold2x2" 0/1  1 (default): the decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) runs as four
  *                  sub-pixel phase convolutions on the low-resolution input with pre-summed weights (9 taps per 4
  *                  outputs instead of 16; an exact regrouping of the sum, rounding differs at the 1e-7 level).

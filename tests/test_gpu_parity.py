@@ -446,7 +446,7 @@ def test_autotuned_tiles_do_not_change_results(published):
     assert np.array_equal(tuned, ref)
 
 
-@pytest.mark.parametrize('fuse', [15, 0])
+@pytest.mark.parametrize('fuse', [31, 15, 0])
 def test_graph_replay_on_changing_inputs(published, fuse):
     """The two-lane hipGraph replay vs eager launches with inputs that CHANGE every forward (a missing edge or a stale
     read in the replayed graph shows up as the previous forward's data; equal inputs would hide it): image and every
@@ -471,3 +471,25 @@ def test_graph_replay_on_changing_inputs(published, fuse):
                 assert np.array_equal(eg.tap(f'aligned{l}'), ee.tap(f'aligned{l}')), (b, h, wd, it, l)
     eg.close()
     ee.close()
+
+
+def test_fused_rgb_head_is_bit_identical(published):
+    """Option fuse bit 16 (the RGB head's 1x1 convolution inside the epilogue of the last decoder layer, whose 64-channel
+    output is then never written) sums in conv_pw_kernel's order: the image has the same bits with and without it."""
+    from film_hip.engine import FilmEngine
+    opt, w, _ = published
+    ef = FilmEngine(opt, device=0)
+    ef.set_weights(w)
+    eu = FilmEngine(opt, device=0)
+    eu.set_weights(w)
+    eu.set_option('fuse', 15)
+    for (b, h, wd) in ((1, 256, 256), (2, 192, 320), (1, 320, 448)):
+        assert any('+output_conv' in op['tag'] for op in ef.plan(b, h, wd)['ops'])
+        assert not any('+output_conv' in op['tag'] for op in eu.plan(b, h, wd)['ops'])
+        rng = np.random.default_rng(h + wd)
+        x0 = rng.random((b, h, wd, 3), dtype=np.float32)
+        x1 = rng.random((b, h, wd, 3), dtype=np.float32)
+        a, c = ef.forward(x0, x1), eu.forward(x0, x1)
+        assert np.array_equal(a, c), (b, h, wd, float(np.abs(a - c).max()))
+    ef.close()
+    eu.close()
