@@ -45,7 +45,7 @@ enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priori
                                // per CU), no weight stores, two barriers per chunk instead of three
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
-__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & 65536) != 0 && BN == 32 && QW == 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
+__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & W43_F_BG) != 0 && BN == 32 && QW == 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
   constexpr int RPT = 32 / QW;                 // patch rows per 32-quad MFMA tile
   constexpr int MT = TH / RPT;                 // MFMA row tiles per patch; TM of them per wave
   constexpr int NU = 6 / NH;                   // nu planes per wave

@@ -34,8 +34,10 @@ def main():
     db = sqlite3.connect(args.db)
     cur = db.cursor()
     rows = [(n, s, e) for n, s, e in cur.execute('select name, start, end from kernels order by start') if ENGINE.search(n)]
-    # conv_pw<3> (the RGB head) runs exactly once per forward and never in autotune
-    heads = [i for i, r in enumerate(rows) if 'conv_pw_kernel<3>' in r[0]]
+    # the last launch of a forward: tiles_to_frame (film_interpolate: once per forward, never in autotune), else the RGB
+    # head conv_pw<3> (film_forward with fuse bit 16 off; with it on the head is part of the last decoder convolution)
+    last = 'tiles_to_frame_kernel' if any('tiles_to_frame_kernel' in r[0] for r in rows) else 'conv_pw_kernel<3>'
+    heads = [i for i, r in enumerate(rows) if last in r[0]]
     if len(heads) < args.forwards:
         sys.exit(f'found {len(heads)} forwards, expected {args.forwards}')
     per_fwd = args.launches_per_forward or (heads[-1] - heads[-2])
