@@ -111,13 +111,15 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   int sg = 0, c0 = 0, segC = p.seg[0].C;
   auto setup_seg = [&]() {
     const ConvSeg& s = p.seg[sg];
-    arsrc = conv_make_rsrc(s.ptr);
     segC = s.C;
     a_pix = (unsigned)s.stride * 4u;
     int be = img + s.boff;
     if (s.bmod && be >= s.bmod) be -= s.bmod;
-    // may point outside the tensor: only dereferenced under a_ok
-    a_off = (unsigned)(((long long)((size_t)be * p.H + a_y) * p.W + a_x) * s.stride + scol) * 4u;
+    // The buffer resource starts at the first halo row of THIS patch (64-bit pointer arithmetic, uniform in the
+    // workgroup); the 32-bit lane offsets only span the patch's TH + 2 rows, so a segment may be larger than 4 GiB (the
+    // level-0 buffers of an untiled 4K frame).  Both may point outside the tensor: only dereferenced under a_ok.
+    arsrc = conv_make_rsrc(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride);
+    a_off = (unsigned)((ahy * p.W + a_x) * s.stride + scol) * 4u;
   };
 
   // ---- B staging ---------------------------------------------------------------------------------------------------

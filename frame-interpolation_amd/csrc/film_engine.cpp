@@ -1177,6 +1177,14 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
       --alive;
     }
     hipError_t e = hipMalloc(&P->arena, (size_t)P->arena_floats * sizeof(float));
+    if (e != hipSuccess && alive > 0) {   // out of memory: give back the other plans' workspaces and try once more
+      (void)hipGetLastError();
+      (void)hipDeviceSynchronize();
+      for (size_t i = h->plans.size(); i-- > 0;)
+        if (h->plans[i]->arena) { free_plan(h->plans[i].get()); h->plans.erase(h->plans.begin() + i); }
+      h->last_plan = nullptr;
+      e = hipMalloc(&P->arena, (size_t)P->arena_floats * sizeof(float));
+    }
     if (e != hipSuccess) {
       P->arena = nullptr;
       return fail(h, FILM_ERR_NOMEM, "workspace hipMalloc of %.1f MB failed: %s", P->arena_floats * 4e-6, hipGetErrorString(e));
@@ -1197,6 +1205,8 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
 // ---------------------------------------------------------------------------------------------
 // JSON helpers
 // ---------------------------------------------------------------------------------------------
+int64_t limited_buffer_bytes(const Plan* P);   // (below, next to the batch-chunking rule)
+
 void json_view(std::ostringstream& o, const char* key, const View& v, const Plan& P) {
   o << "\"" << key << "\":{\"buf\":\"" << (v.buf >= 0 ? P.bufs[v.buf].name : std::string("")) << "\",\"off\":" << v.off
     << ",\"stride\":" << v.stride << ",\"C\":" << v.C << "}";
@@ -1205,6 +1215,7 @@ void json_view(std::ostringstream& o, const char* key, const View& v, const Plan
 std::string plan_json(film_t* h, const Plan& P) {
   std::ostringstream o;
   o << "{\"B\":" << P.B << ",\"H\":" << P.H << ",\"W\":" << P.W << ",\"arena_floats\":" << P.arena_floats
+    << ",\"offset32_buffer_bytes\":" << limited_buffer_bytes(&P)
     << ",\"packed_floats\":" << h->packed_floats << ",\"buffers\":[";
   for (size_t i = 0; i < P.bufs.size(); ++i) {
     const Buffer& b = P.bufs[i];
@@ -1760,17 +1771,31 @@ int film_profile_json(film_t* h, char* buf, int64_t cap, int64_t* needed) {
 }
 
 namespace {
-// The conv kernel addresses its inputs with 32-bit byte offsets (buffer loads): every activation buffer of a plan
-// must stay below 4 GiB.  Largest buffer of a B = 1 plan, in bytes (buffers scale linearly with the batch).
-int64_t unit_buffer_bytes(film_t* h, int H, int W, int* rc) {
-  Plan* P1 = nullptr;
-  *rc = get_plan(h, 1, H, W, false, &P1);
-  if (*rc) return 0;
-  int64_t mx = 0;
-  for (const Buffer& b : P1->bufs) mx = std::max(mx, b.floats * (int64_t)sizeof(float));
+// The conv kernels other than conv_wino43_kernel address their inputs with 32-bit byte offsets from the start of the
+// buffer (buffer loads): every activation buffer THEY read must stay below 4 GiB.  conv_wino43_kernel addresses relative
+// to the workgroup's own halo rows and every other kernel with 64-bit pointers, so the large levels of a large frame
+// (F(4,3) layers only: an untiled 4K frame has 4.4-5 GB level-0 buffers) are not limited.  Largest limited buffer of a
+// B = 1 plan, in bytes (buffers scale linearly with the batch; the kernel family of a layer does not depend on it).
+int64_t limited_buffer_bytes(const Plan* P) {
+  int64_t mx = 1;
+  for (const OpDesc& op : P->ops) {
+    if (op.kind != OP_CONV || op.wino == 3) continue;
+    for (int i = 0; i < op.nseg; ++i) mx = std::max(mx, P->bufs[op.seg[i].v.buf].floats * (int64_t)sizeof(float));
+  }
   return mx;
 }
 constexpr int64_t kMaxBufferBytes = 0xFFF00000ll;
+// One model invocation also keeps its workspace below this (a fifth of the HBM): 15 tiles of 960x576, one untiled 4K frame
+constexpr int64_t kMaxArenaBytes = 64ll << 30;
+int64_t unit_buffer_bytes(film_t* h, int H, int W, int* rc, int* max_units) {
+  Plan* P1 = nullptr;
+  *rc = get_plan(h, 1, H, W, false, &P1);
+  if (*rc) return 0;
+  const int64_t lim = limited_buffer_bytes(P1);
+  const int64_t arena = std::max<int64_t>(1, P1->arena_floats * (int64_t)sizeof(float));
+  *max_units = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBufferBytes / lim, kMaxArenaBytes / arena));
+  return lim;
+}
 
 int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream);
 int run_plan(film_t* h, Plan* P, hipStream_t s);
@@ -1784,12 +1809,12 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
   if (mem_kind != FILM_MEM_HOST && mem_kind != FILM_MEM_DEVICE) return fail(h, FILM_ERR_INVALID, "bad mem_kind");
   if (B < 1) return fail(h, FILM_ERR_INVALID, "B, H, W must be positive");
   int rc = 0;
-  const int64_t unit = unit_buffer_bytes(h, H, W, &rc);
+  int bmax = 1;
+  const int64_t unit = unit_buffer_bytes(h, H, W, &rc, &bmax);
   if (rc) return rc;
   if (unit > kMaxBufferBytes)
-    return fail(h, FILM_ERR_INVALID, "a %d x %d frame needs a %.1f GB activation buffer; the conv kernel addresses 4 GiB per "
+    return fail(h, FILM_ERR_INVALID, "a %d x %d frame needs a %.1f GB activation buffer in front of a kernel that addresses 4 GiB per "
                 "buffer - tile the frame (Interpolator block_shape)", H, W, unit * 1e-9);
-  int bmax = (int)std::max<int64_t>(1, kMaxBufferBytes / unit);
   if (h->opt_max_batch) bmax = std::min(bmax, h->opt_max_batch);
   const size_t frame = (size_t)H * W * 3;
   for (int b0 = 0; b0 < B; b0 += bmax) {  // independent frame pairs: the batch splits with no change in results
@@ -1818,13 +1843,13 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
   tp.TH = tp.ph + hp; tp.TW = tp.pw + wp; tp.oy = hp / 2; tp.ox = wp / 2;
   HIPCHK(h, hipSetDevice(h->device));
   int rc = 0;
-  const int64_t unit = unit_buffer_bytes(h, tp.TH, tp.TW, &rc);
+  int tmax = 1;
+  const int64_t unit = unit_buffer_bytes(h, tp.TH, tp.TW, &rc, &tmax);
   if (rc) return rc;
   if (unit > kMaxBufferBytes)
-    return fail(h, FILM_ERR_INVALID, "a %d x %d tile needs a %.1f GB activation buffer; the conv kernel addresses 4 GiB per "
+    return fail(h, FILM_ERR_INVALID, "a %d x %d tile needs a %.1f GB activation buffer in front of a kernel that addresses 4 GiB per "
                 "buffer - use a finer block_shape", tp.TH, tp.TW, unit * 1e-9);
   const int ntiles = B * bh * bw;
-  int tmax = (int)std::max<int64_t>(1, kMaxBufferBytes / unit);
   if (h->opt_max_batch) tmax = std::min(tmax, h->opt_max_batch);
   hipStream_t s = pick_stream(h, mem_kind, stream);
   const size_t frame_bytes = (size_t)B * H * W * 3 * sizeof(float);

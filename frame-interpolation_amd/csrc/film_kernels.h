@@ -23,7 +23,8 @@ struct ConvSeg {
 
 // Conv2D(padding='same', stride 1) [+ bias] [+ leaky_relu(0.2)] as implicit GEMM:
 //   M = NB*H*W output pixels, N = Cout, K = ksize^2 * Ctot, K ordered (tap, segment, channel).
-// Every segment is addressed with 32-bit byte offsets from seg.ptr: the buffer behind it must be < 4 GiB.
+// Every segment is addressed with 32-bit byte offsets from seg.ptr: the buffer behind it must be < 4 GiB - except in
+// conv_wino43_kernel, whose buffer resource starts at the workgroup's own first halo row (any size).
 struct ConvParams {
   ConvSeg seg[FILM_MAX_SEG];
   int nseg;

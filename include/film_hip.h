@@ -119,7 +119,8 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
  * align <= 0 means no padding (the reference's align=None); H, W (or the patch) must then be divisible by
  * 2^(pyramid_levels-1).  Pad / patch / crop / stitch are two HIP kernels that read the caller's frames and write
  * the plan's input buffer directly (and back), so with FILM_MEM_DEVICE nothing but the frames themselves is copied.
- * Batches whose activation buffers would exceed 4 GiB are processed in chunks of tiles (results unchanged).
+ * Batches are processed in chunks of tiles that keep one invocation's workspace below 64 GiB and every buffer read through a
+ * 32-bit whole-buffer offset below 4 GiB (results unchanged).
  * `stream` and mem_kind as for film_forward. */
 int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, int W, int align, int block_h,
                      int block_w, float* out, int mem_kind, void* stream);

@@ -243,3 +243,27 @@ def test_rccl_broadcast_path_single_rank(published):
         e2.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_untiled_4k_frame_with_buffers_above_4gib(published):
+    """ONE untiled 3840x2240 pair (film_forward, no block_shape): feat0 / warped0 are 4.4 GB and aligned0 4.95 GB, beyond
+    what a 32-bit buffer offset reaches - conv_wino43_kernel addresses relative to each workgroup's own halo rows.
+    Against the committed oracle fixture (tools/make_big_golden.py: stride-16 sample + float64 row / column sums of the
+    full image; the oracle itself needs minutes and ~30 GB of host memory for this frame)."""
+    import inputs
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'oracle_big_untiled.npz'))
+    _, h, w, _ = (int(v) for v in g['shape'])
+    opt, wts, eng = published
+    x0, x1 = inputs.frame_pair(1, h, w, 41)
+    assert np.allclose([x0.astype(np.float64).sum(), x1.astype(np.float64).sum()], g['in_checksum'], rtol=0, atol=1e-6)
+    plan = eng.plan(1, h, w)
+    assert max(b['floats'] for b in plan['buffers']) * 4 > 2 ** 32
+    got = eng.forward(x0, x1)
+    st = int(g['stride'])
+    d = float(np.abs(got[:, ::st, ::st, :] - g['sample']).max())
+    rows = float(np.abs(got.astype(np.float64).sum(axis=2) - g['rowsum']).max() / w)
+    cols = float(np.abs(got.astype(np.float64).sum(axis=1) - g['colsum']).max() / h)
+    print(f'untiled {h}x{w}: hip vs oracle fixture sample max|d| {d:.3e}, row sums {rows:.3e}, column sums {cols:.3e} per pixel')
+    assert d < IMAGE_TOL and rows < IMAGE_TOL and cols < IMAGE_TOL
+    # the bottom rows are the ones behind the 4 GiB mark of the level-0 buffers
+    assert float(np.abs(got[:, -64::st, ::st, :] - g['sample'][:, -(64 // st):]).max()) < IMAGE_TOL

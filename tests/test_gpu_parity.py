@@ -374,7 +374,7 @@ def test_winograd_kernel_on_every_level(published, precision, b, h, w):
 
 def test_4k_frame_crosses_the_4gib_buffer_rule(published):
     """BASELINE configs[4] geometry: a 3840x2160 pair with 4x4 blocks = 16 tiles of 960x576.  One model invocation may
-    hold at most floor(4 GiB / largest activation buffer) tiles (13 here), so film_interpolate runs two chunks; the
+    hold at most 15 tiles of this size (64 GiB of workspace), so film_interpolate runs two chunks; the
     result must be bit-identical to running the tiles four at a time."""
     opt, w, eng = published
     rng = np.random.default_rng(59)

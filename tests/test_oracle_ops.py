@@ -200,3 +200,23 @@ def test_pad_crop_roundtrip(size, off):
     assert p.shape[1] % 64 == 0 and box['offset_height'] == off
     assert np.array_equal(p[:, off:off + size, box['offset_width']:box['offset_width'] + 16], x)
     assert not p[:, :off].any() and not p[:, off + size:].any()
+
+
+def test_lean_forward_of_the_big_golden_script_is_the_oracle_forward():
+    """tools/make_big_golden.py assembles the aligned pyramid level by level to fit a 3840x2240 frame into host memory; on
+    a small frame it must give the bits of oracle.film_oracle.film_forward."""
+    import importlib.util
+    import os
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+    spec = importlib.util.spec_from_file_location('make_big_golden', os.path.join(root, 'tools', 'make_big_golden.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    from oracle import film_oracle as fo
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    rng = np.random.default_rng(5)
+    x0 = rng.random((2, 64, 128, 3), dtype=np.float32)
+    x1 = rng.random((2, 64, 128, 3), dtype=np.float32)
+    assert np.array_equal(mod.film_forward_lean(x0, x1, w, fo.Options()), fo.film_forward(x0, x1, w, fo.Options()))

@@ -340,3 +340,30 @@ def test_plan_interpreter_fused_ops_published_256():
             arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
             assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
     assert counts[0] - counts[31] >= 26, counts
+
+
+def test_untiled_4k_frame_only_f43_layers_read_the_buffers_above_4gib():
+    """An untiled 3840x2240 pair has 4.4-5 GB level-0 buffers.  Only conv_wino43_kernel (addresses relative to a workgroup's
+    own halo rows) and the 64-bit-pointer kernels may read them; everything behind a 32-bit whole-buffer offset
+    (`offset32_buffer_bytes`, what film_forward checks and chunks batches by) stays below 4 GiB."""
+    from film_hip.engine import FilmEngine
+    from film_hip.options import PUBLISHED
+    eng = FilmEngine(PUBLISHED, device=-1)
+    plan = eng.plan(1, 2240, 3840)
+    size = {b['name']: b['floats'] * 4 for b in plan['buffers']}
+    lim = 0xFFF00000
+    assert max(size.values()) > 2 ** 32 and plan['offset32_buffer_bytes'] < lim
+    big_readers = 0
+    for op in plan['ops']:
+        if op['kind'] != 'conv_mfma':
+            continue
+        for sg in op['segs']:
+            if size[sg['v']['buf']] > lim:
+                assert op['wino'] == 3, (op['tag'], sg['v']['buf'])
+                big_readers += 1
+            elif op['wino'] != 3:
+                assert size[sg['v']['buf']] <= plan['offset32_buffer_bytes']
+    assert big_readers >= 5
+    # 8K untiled: a direct-convolution layer would have to read more than 4 GiB -> refused (tile it)
+    assert eng.plan(1, 4352, 7680)['offset32_buffer_bytes'] > lim
+    eng.close()
