@@ -2033,6 +2033,10 @@ int film_get_tap(film_t* h, const char* name, float* dst, int64_t cap, int64_t d
   const int bi = P->find(name);
   if (bi < 0) return fail(h, FILM_ERR_NOTFOUND, "unknown tap '%s'", name);
   const Buffer& b = P->bufs[bi];
+  for (const OpDesc& op : P->ops)   // a fused 1x1 head keeps this activation on chip: nothing ever writes the buffer
+    if (op.kind == OP_CONV && op.pw_out.buf >= 0 && op.out.buf == bi)
+      return fail(h, FILM_ERR_STATE, "tap '%s' is not materialised: the RGB head is fused into the layer that produces it "
+                  "(film_set_option \"fuse\" without bit 16 keeps it)", name);
   if (dims) { dims[0] = b.N; dims[1] = b.H; dims[2] = b.W; dims[3] = b.C; }
   if (!dst) return FILM_OK;  // shape query
   if (cap < b.size()) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)b.size());

@@ -491,5 +491,10 @@ def test_fused_rgb_head_is_bit_identical(published):
         x1 = rng.random((b, h, wd, 3), dtype=np.float32)
         a, c = ef.forward(x0, x1), eu.forward(x0, x1)
         assert np.array_equal(a, c), (b, h, wd, float(np.abs(a - c).max()))
+    # the last decoder activation never reaches memory in the fused plan: its tap says so instead of returning zeros
+    from film_hip.engine import FilmError
+    with pytest.raises(FilmError):
+        ef.tap('fusion_b0')
+    assert np.abs(eu.tap('fusion_b0')).max() > 0
     ef.close()
     eu.close()
