@@ -6,7 +6,7 @@ it: a stride-16 pixel sample of the image + float64 row / column sums of the ful
 Inputs: tests/inputs.frame_pair(1, 2240, 3840, seed=41) and film_hip.weights.make_synthetic_weights(PUBLISHED, seed=0),
 both seeded, so nothing but the output is stored.
 
-  python tools/make_big_golden.py            # ~5-10 minutes on 8 cores
+  python tools/make_big_golden.py            # 64 minutes on 8 cores, 23 GB
 """
 import os
 import sys
