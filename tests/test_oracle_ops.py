@@ -217,6 +217,6 @@ def test_lean_forward_of_the_big_golden_script_is_the_oracle_forward():
     from oracle import film_oracle as fo
     w = W.make_synthetic_weights(PUBLISHED, seed=0)
     rng = np.random.default_rng(5)
-    x0 = rng.random((2, 64, 128, 3), dtype=np.float32)
-    x1 = rng.random((2, 64, 128, 3), dtype=np.float32)
+    x0 = rng.random((1, 64, 64, 3), dtype=np.float32)
+    x1 = rng.random((1, 64, 64, 3), dtype=np.float32)
     assert np.array_equal(mod.film_forward_lean(x0, x1, w, fo.Options()), fo.film_forward(x0, x1, w, fo.Options()))

@@ -150,21 +150,30 @@ def test_plan_interpreter_matches_oracle_tiny(tiny_weights, b, h, w):
     assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 1e-5
 
 
-def test_plan_interpreter_matches_oracle_published_64():
+@pytest.fixture(scope='module')
+def published_packed():
+    """(weights, plan-only engine of the published net with all four layout groups packed, the exported layout blob):
+    1.1 GB of packing + export that the interpreter tests share."""
     from film_hip import weights as W
     from film_hip.engine import FilmEngine
     from film_hip.options import PUBLISHED
-    from oracle import film_oracle as fo
-    import plan_interp as pi
     w = W.make_synthetic_weights(PUBLISHED, seed=0)
     eng = FilmEngine(PUBLISHED, device=-1)
     eng.set_weights(w)
-    eng.set_option('pack_groups', 4)
+    eng.set_option('pack_groups', 4)     # every layout copy, so that the interpreter can check all of them
+    yield w, eng, eng.export_layouts()
+    eng.close()
+
+
+def test_plan_interpreter_matches_oracle_published_64(published_packed):
+    from oracle import film_oracle as fo
+    import plan_interp as pi
+    w, eng, layouts = published_packed
     plan = eng.plan(1, 64, 64)
     rng = np.random.default_rng(3)
     x0 = rng.random((1, 64, 64, 3), dtype=np.float32)
     x1 = rng.random((1, 64, 64, 3), dtype=np.float32)
-    arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
+    arena = pi.run_plan(plan, layouts, x0, x1)
     want = fo.film_forward(x0, x1, w, fo.Options())
     assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
     # algorithmic conv FLOPs of the plan == SURVEY.md 8(d): 4 246 240.6875 FLOP per padded pixel
@@ -309,36 +318,33 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
                     assert i in before[j], (ops[i]['tag'], ops[j]['tag'])
 
 
-def test_plan_interpreter_fused_ops_published_256():
+def test_plan_interpreter_fused_ops_published_256(published_packed):
     """The default plan of a 256x256 pair carries every fusion (fuse = 31): flow upsample inside the warps, v = res + up
     inside the flow heads, image warps inside the feature warps, average pools inside the F(4,3) convolutions, the RGB head
     inside the last decoder convolution - and the
     interpreter, which gives each fused op the semantics of the separate reference ops, still reproduces the oracle.
     With fuse = 0 the plan has one op per reference op and the same result."""
-    from film_hip import weights as W
-    from film_hip.engine import FilmEngine
-    from film_hip.options import PUBLISHED
     from oracle import film_oracle as fo
     import plan_interp as pi
-    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    w, eng, layouts = published_packed
     rng = np.random.default_rng(9)
     x0 = rng.random((1, 256, 256, 3), dtype=np.float32)
     x1 = rng.random((1, 256, 256, 3), dtype=np.float32)
     want = fo.film_forward(x0, x1, w, fo.Options())
     counts = {}
-    for fuse in (31, 0):
-        eng = FilmEngine(PUBLISHED, device=-1)
-        eng.set_weights(w)
-        eng.set_option('fuse', fuse)
-        eng.set_option('pack_groups', 4)     # the interpreter checks every weight copy an op could read
-        plan = eng.plan(1, 256, 256)
-        tags = [op['tag'] for op in plan['ops']]
-        counts[fuse] = len(tags)
-        for mark in ('+pool', '+img', '+flows', '+resize2x', '+v=res+up', '+output_conv'):
-            assert any(mark in t for t in tags) == (fuse == 31), (fuse, mark)
-        if fuse == 31:      # (an unfused plan is interpreted by test_plan_interpreter_matches_oracle_tiny[2-32-48])
-            arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
-            assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
+    try:
+        for fuse in (0, 31):
+            eng.set_option('fuse', fuse)
+            plan = eng.plan(1, 256, 256)
+            tags = [op['tag'] for op in plan['ops']]
+            counts[fuse] = len(tags)
+            for mark in ('+pool', '+img', '+flows', '+resize2x', '+v=res+up', '+output_conv'):
+                assert any(mark in t for t in tags) == (fuse == 31), (fuse, mark)
+            if fuse == 31:      # (an unfused plan is interpreted by test_plan_interpreter_matches_oracle_tiny[2-32-48])
+                arena = pi.run_plan(plan, layouts, x0, x1)
+                assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 2e-5
+    finally:
+        eng.set_option('fuse', 31)
     assert counts[0] - counts[31] >= 26, counts
 
 
