@@ -168,8 +168,9 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.
- *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in
- *                  4 GiB-per-activation-buffer limit); frame pairs are independent, results do not change */
+ *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in limits: 64 GiB of
+ *                  workspace, 4 GiB per buffer read through a whole-buffer 32-bit offset); frame pairs are independent,
+ *                  results do not change */
 int film_set_option(film_t* h, const char* key, int64_t value);
 
 /* Per-kernel-class timing of the last profiled forward as JSON
@@ -179,7 +180,8 @@ int film_profile_json(film_t* h, char* buf, int64_t capacity, int64_t* needed);
 /* Description of the plan for (B,H,W) as JSON: named workspace buffers (offset, dims),
  * the op list with every kernel parameter and the packed-weight offsets.  Works on
  * plan-only handles; tests interpret it against a numpy arena to validate planner and
- * weight packing without a GPU. */
+ * weight packing without a GPU.  "offset32_buffer_bytes" = the largest buffer a kernel with whole-buffer 32-bit
+ * offsets reads (must stay below 4 GiB; conv_wino43_kernel and the pointer-addressed kernels are not limited). */
 int film_plan_json(film_t* h, int B, int H, int W, char* buf, int64_t capacity, int64_t* needed);
 
 /* Copies a named workspace buffer of the last forward (see "buffers" in film_plan_json) to a
