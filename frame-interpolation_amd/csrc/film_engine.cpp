@@ -182,6 +182,8 @@ struct film_handle {
   int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs; 2: bf16x3
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
+  std::map<std::string, int> tune_import; // choices of an earlier process (film_import_tune): taken, if still a candidate of
+                                          // the op's kernel family, instead of timing the candidates again
 };
 
 extern "C" int film_ensure_groups_(film_t* h, int n);   // packs + uploads weight layout groups [groups_packed, n) on demand (internal)
@@ -1074,10 +1076,35 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // Measure, don't guess: every distinct conv shape of a plan is timed once with each tile shape that fits
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
+std::vector<int> conv_candidates(const OpDesc& op) {
+  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  if (op.c3) {
+    // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
+    // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
+    cands.clear();
+    if (op.Cout == 64 || op.Cout == 32) cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
+    else
+      for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
+        cands.push_back(sh | CONV_TILE_C3);
+        cands.push_back(sh | CONV_TILE_C3 | CONV_TILE_XCD);
+      }
+  }
+  return cands;
+}
+
 int autotune_plan(film_t* h, Plan* P) {
   bool need = false;
-  for (const OpDesc& op : P->ops)
-    if (op.kind == OP_CONV && !h->tune_cache.count(conv_signature(op))) need = true;
+  for (const OpDesc& op : P->ops) {
+    if (op.kind != OP_CONV) continue;
+    const std::string sig = conv_signature(op);
+    if (h->tune_cache.count(sig)) continue;
+    auto it = h->tune_import.find(sig);
+    if (it != h->tune_import.end()) {   // an earlier process measured this shape: keep its choice if it is still a candidate
+      const std::vector<int> cands = conv_candidates(op);
+      if (std::find(cands.begin(), cands.end(), it->second) != cands.end()) { h->tune_cache[sig] = it->second; continue; }
+    }
+    need = true;
+  }
   if (need) {
     HIPCHK(h, film_launch_fill_random(P->arena, P->arena_floats, 0x9e3779b9u, h->stream));
     hipEvent_t e0, e1;
@@ -1089,18 +1116,7 @@ int autotune_plan(film_t* h, Plan* P) {
       if (h->tune_cache.count(sig)) continue;
       int best = op.tile;
       float best_ms = 1e30f;
-      std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
-      if (op.c3) {
-        // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
-        // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
-        cands.clear();
-        if (op.Cout == 64 || op.Cout == 32) cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
-        else
-          for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
-            cands.push_back(sh | CONV_TILE_C3);
-            cands.push_back(sh | CONV_TILE_C3 | CONV_TILE_XCD);
-          }
-      }
+      const std::vector<int> cands = conv_candidates(op);
       for (int tile : cands) {
         OpDesc trial = op;
         trial.tile = tile;
@@ -1768,6 +1784,43 @@ int film_profile_json(film_t* h, char* buf, int64_t cap, int64_t* needed) {
   if (!h) return FILM_ERR_INVALID;
   if (h->profile_json.empty()) return fail(h, FILM_ERR_STATE, "no profiled forward yet (film_set_option(\"profile\", 1))");
   return copy_out_string(h, h->profile_json, buf, cap, needed);
+}
+
+// Autotune choices as text: a header line with the library version, then one "<conv shape signature>\t<tile id>" line per
+// measured shape (this handle's own measurements + imported ones it has not needed yet).
+int film_export_tune(film_t* h, char* buf, int64_t cap, int64_t* needed) {
+  if (!h) return FILM_ERR_INVALID;
+  std::ostringstream o;
+  o << "# film_hip tune cache v1 " << film_version() << "\n";
+  std::map<std::string, int> all = h->tune_import;
+  for (const auto& kv : h->tune_cache) all[kv.first] = kv.second;
+  for (const auto& kv : all) o << kv.first << '\t' << kv.second << '\n';
+  return copy_out_string(h, o.str(), buf, cap, needed);
+}
+
+// Takes the text of film_export_tune.  A cache written by another library version is ignored (returns FILM_OK, imports
+// nothing: tile ids are only meaningful within one build); entries are validated when a plan first needs them - a tile
+// that is not a candidate of the op's kernel family is measured again.  Results never depend on the cache: every tile of
+// a family produces the same bits.
+int film_import_tune(film_t* h, const char* text) {
+  if (!h || !text) return fail(h, FILM_ERR_INVALID, "NULL argument");
+  std::istringstream in(text);
+  std::string line;
+  if (!std::getline(in, line)) return FILM_OK;
+  const std::string want = std::string("# film_hip tune cache v1 ") + film_version();
+  if (line != want) return FILM_OK;
+  std::map<std::string, int> got;
+  while (std::getline(in, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    const size_t tab = line.rfind('\t');
+    if (tab == std::string::npos || tab == 0 || tab + 1 >= line.size()) return fail(h, FILM_ERR_INVALID, "tune cache: malformed line '%s'", line.c_str());
+    char* end = nullptr;
+    const long tile = strtol(line.c_str() + tab + 1, &end, 10);
+    if (*end != 0 || tile < 0 || tile > (1 << 20)) return fail(h, FILM_ERR_INVALID, "tune cache: malformed line '%s'", line.c_str());
+    got[line.substr(0, tab)] = (int)tile;
+  }
+  for (const auto& kv : got) h->tune_import[kv.first] = kv.second;
+  return FILM_OK;
 }
 
 namespace {

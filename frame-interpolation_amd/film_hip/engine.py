@@ -44,7 +44,8 @@ EXPORTED_SYMBOLS = (
     'film_default_config', 'film_create', 'film_destroy', 'film_last_error', 'film_set_weight',
     'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_export_layouts', 'film_forward',
     'film_interpolate',
-    'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version')
+    'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version',
+    'film_export_tune', 'film_import_tune')
 
 _lib = None
 
@@ -92,6 +93,8 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_crc32c.restype = ctypes.c_uint32
     lib.film_version.argtypes = []
     lib.film_version.restype = cp
+    lib.film_export_tune.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, i64p]
+    lib.film_import_tune.argtypes = [vp, cp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ('film_destroy',):
@@ -158,6 +161,47 @@ class FilmEngine:
             dims = (ctypes.c_int64 * a.ndim)(*a.shape)
             self._check(self._lib.film_set_weight(self._h, name.encode(), a.ctypes.data, dims, a.ndim))
         self._check(self._lib.film_finalize(self._h))
+        self._load_tune_cache()
+
+    # -- autotune choices across processes ($FILM_TUNE_CACHE = a file path) --------------------------------
+    def export_tune(self) -> str:
+        need = ctypes.c_int64()
+        self._check(self._lib.film_export_tune(self._h, None, 0, ctypes.byref(need)))
+        buf = ctypes.create_string_buffer(need.value)
+        self._check(self._lib.film_export_tune(self._h, buf, need.value, ctypes.byref(need)))
+        return buf.value.decode()
+
+    def import_tune(self, text: str) -> None:
+        self._check(self._lib.film_import_tune(self._h, text.encode()))
+
+    def _load_tune_cache(self) -> None:
+        path = os.environ.get('FILM_TUNE_CACHE')
+        self._tune_saved = None
+        if path and os.path.isfile(path):
+            try:
+                with open(path) as f:
+                    self.import_tune(f.read())
+                self._tune_saved = self.export_tune()
+            except (OSError, FilmError):
+                pass      # an unreadable / malformed cache only costs the measurements again
+
+    def save_tune_cache(self) -> None:
+        """Writes the autotune choices to $FILM_TUNE_CACHE if they changed (atomic rename; called after every
+        host-buffer forward, call it yourself after warming up a device-resident pipeline)."""
+        path = os.environ.get('FILM_TUNE_CACHE')
+        if not path or self.device < 0:
+            return
+        text = self.export_tune()
+        if text == getattr(self, '_tune_saved', None):
+            return
+        tmp = f'{path}.{os.getpid()}.tmp'
+        try:
+            with open(tmp, 'w') as f:
+                f.write(text)
+            os.replace(tmp, path)
+            self._tune_saved = text
+        except OSError:
+            pass
 
     def packed_size(self) -> int:
         n = ctypes.c_int64()
@@ -180,9 +224,11 @@ class FilmEngine:
     def import_packed(self, blob: np.ndarray) -> None:
         b = np.ascontiguousarray(blob, dtype=np.float32)
         self._check(self._lib.film_import_packed(self._h, b.ctypes.data, b.size, FILM_MEM_HOST))
+        self._load_tune_cache()
 
     def import_packed_device(self, ptr: int, n_floats: int) -> None:
         self._check(self._lib.film_import_packed(self._h, ctypes.c_void_p(ptr), n_floats, FILM_MEM_DEVICE))
+        self._load_tune_cache()
 
     def export_packed_device(self, ptr: int, n_floats: int) -> None:
         self._check(self._lib.film_export_packed(self._h, ctypes.c_void_p(ptr), n_floats, FILM_MEM_DEVICE))
@@ -198,6 +244,7 @@ class FilmEngine:
         out = np.empty_like(x0)
         self._check(self._lib.film_forward(self._h, x0.ctypes.data, x1.ctypes.data, b, h, w,
                                            out.ctypes.data, FILM_MEM_HOST, None))
+        self.save_tune_cache()
         return out
 
     def forward_device(self, x0_ptr: int, x1_ptr: int, b: int, h: int, w: int, out_ptr: int,
@@ -221,6 +268,7 @@ class FilmEngine:
         out = np.empty_like(x0)
         self._check(self._lib.film_interpolate(self._h, x0.ctypes.data, x1.ctypes.data, b, h, w, int(align or 0),
                                                bh, bw, out.ctypes.data, FILM_MEM_HOST, None))
+        self.save_tune_cache()
         return out
 
     def interpolate_frames_device(self, x0_ptr: int, x1_ptr: int, b: int, h: int, w: int, out_ptr: int,

@@ -173,6 +173,15 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  results do not change */
 int film_set_option(film_t* h, const char* key, int64_t value);
 
+/* Autotune choices across processes.  film_export_tune writes text (buf / capacity / needed as film_plan_json): a header
+ * line with the library version, then "<conv shape signature>\t<tile id>" per shape this handle measured or imported.
+ * film_import_tune takes such text before the first forward: shapes found in it are not measured again (first call of a
+ * 1080p plan 2.5 s -> the plan build + graph capture alone).  Text from another library version is ignored, entries are
+ * validated against the kernel family of the op that wants them, and results never depend on the cache (every tile of a
+ * family produces the same bits).  film_hip.engine reads / writes the file named by $FILM_TUNE_CACHE with these. */
+int film_export_tune(film_t* h, char* buf, int64_t capacity, int64_t* needed);
+int film_import_tune(film_t* h, const char* text);
+
 /* Per-kernel-class timing of the last profiled forward as JSON
  * {"classes": {"conv_mfma": {"launches": n, "ms": t, "flops": f, "bytes": b}, ...}}. */
 int film_profile_json(film_t* h, char* buf, int64_t capacity, int64_t* needed);

@@ -498,3 +498,34 @@ def test_fused_rgb_head_is_bit_identical(published):
     assert np.abs(eu.tap('fusion_b0')).max() > 0
     ef.close()
     eu.close()
+
+
+def test_tune_cache_carries_autotune_choices_to_the_next_engine(published, tmp_path, monkeypatch):
+    """$FILM_TUNE_CACHE: the first engine measures the tile candidates of every conv shape and writes its choices, the
+    second one reads them and skips the measurements - same tiles in its plan, same bits, a faster first call."""
+    import time
+    from film_hip.engine import FilmEngine
+    opt, w, _ = published
+    path = tmp_path / 'tune.txt'
+    monkeypatch.setenv('FILM_TUNE_CACHE', str(path))
+    rng = np.random.default_rng(77)
+    x0 = rng.random((1, 192, 256, 3), dtype=np.float32)
+    x1 = rng.random((1, 192, 256, 3), dtype=np.float32)
+    first = FilmEngine(opt, device=0)
+    first.set_weights(w)
+    t0 = time.perf_counter()
+    a = first.forward(x0, x1)
+    t_first = time.perf_counter() - t0
+    assert path.is_file() and len(path.read_text().splitlines()) > 20
+    tiles_a = [(op['tag'], op['tile']) for op in first.plan(1, 192, 256)['ops'] if op['kind'] == 'conv_mfma']
+    first.close()
+    second = FilmEngine(opt, device=0)
+    second.set_weights(w)                      # reads the cache
+    t0 = time.perf_counter()
+    b = second.forward(x0, x1)
+    t_second = time.perf_counter() - t0
+    tiles_b = [(op['tag'], op['tile']) for op in second.plan(1, 192, 256)['ops'] if op['kind'] == 'conv_mfma']
+    second.close()
+    print(f'first call with measurements {t_first:.2f} s, with the cache {t_second:.2f} s')
+    assert tiles_a == tiles_b and np.array_equal(a, b)
+    assert t_second < t_first

@@ -373,3 +373,23 @@ def test_untiled_4k_frame_only_f43_layers_read_the_buffers_above_4gib():
     # 8K untiled: a direct-convolution layer would have to read more than 4 GiB -> refused (tile it)
     assert eng.plan(1, 4352, 7680)['offset32_buffer_bytes'] > lim
     eng.close()
+
+
+def test_tune_cache_text_round_trip_and_validation(tiny_weights):
+    """film_export_tune / film_import_tune (autotune choices across processes): text with a version header; another
+    version's text is ignored, malformed lines are refused, imported entries come back out."""
+    from film_hip.engine import FilmEngine, FilmError, load_library
+    from film_hip.options import TINY
+    eng = FilmEngine(TINY, device=-1)
+    eng.set_weights(tiny_weights)
+    head = eng.export_tune()
+    assert head == '# film_hip tune cache v1 ' + load_library().film_version().decode() + '\n'
+    text = head + '2x64x64:16:3:16:0:0:0:0:0:1:0:0|16,16,0,0\t3\n' + '4x32x32:8:3:8:0:0:0:0:0:1:0:0|8,8,0,0\t19\n'
+    eng.import_tune(text)
+    assert eng.export_tune() == head + ''.join(sorted(text.splitlines(True)[1:]))
+    eng.import_tune('# film_hip tune cache v1 some-other-build\nabc\t5\n')      # ignored, not an error
+    assert 'abc' not in eng.export_tune()
+    for bad in (head + 'no tab here\n', head + 'sig\tnot-a-number\n', head + 'sig\t-4\n'):
+        with pytest.raises(FilmError):
+            eng.import_tune(bad)
+    eng.close()
