@@ -24,6 +24,13 @@ Extra objects in the JSON line:
                timed on this host's cores on ONE real 960x576 tile of the workload (a frame is four such
                tiles run one after the other, as the reference's tile loop does): frames/s = 1 / (4 t).
 
+Workloads (`--workload`): the default `1080p_2x2` is BASELINE configs[2], the configuration the metric is quoted on.
+`4k_4x4_T6` is configs[4]: one 3840x2160 pair, 4x4 tiles, `--times_to_interpolate 6` - a step is the WHOLE recursion
+(63 generated frames x 16 tiles = 1008 tile-forwards of 960x576, breadth first on the device); `value` = generated
+frames / s and `ms_per_depth` lists the six depths.  `--scaling strong` (tiled workloads) shards the TILES of the one
+pair over the ranks for the whole recursion tree (film_hip.sharding.TileShardedRecursion: no collective until the
+final gather of the generated tiles to rank 0, which is inside the timed region): total work fixed, "scaling": "strong".
+
 `--gpus N` without a torchrun environment re-executes itself under `python -m torch.distributed.run` with N
 ranks (one per GPU, 127.0.0.1 rendezvous) and refuses to run when fewer than N GPUs are visible; `n_gpus` in
 the line is the number of ranks that actually reported.  `--plan-only` drives the same launcher / broadcast /
@@ -58,7 +65,15 @@ WORKLOADS = {
     'photos': (768, 1024, 64, None, (768, 1024), 1),
     # BASELINE configs[3]: a batch of Vimeo-90K sized pairs per GPU (8 pairs per step per GPU)
     'vimeo_b8': (256, 448, 64, None, (256, 448), 8),
+    # BASELINE configs[4]: 3840x2160 pair, 4x4 tiles of 960x540 (padded to 960x576), times_to_interpolate = 6
+    '4k_4x4_T6': (2160, 3840, 64, [4, 4], (576, 960), 16),
+    # the same recursion at a depth that fits a quick run (tests, smoke runs of the recursion driver)
+    '4k_4x4_T2': (2160, 3840, 64, [4, 4], (576, 960), 16),
+    '1080p_2x2_T3': (1080, 1920, 64, [2, 2], (576, 960), 4),
 }
+RECURSIONS = {'4k_4x4_T6': 6, '4k_4x4_T2': 2, '1080p_2x2_T3': 3}   # times_to_interpolate (1 everywhere else)
+METRIC = {'4k_4x4_T6': 'interpolated frames/sec @4K (4x4 tiles, times_to_interpolate 6)',
+          '4k_4x4_T2': 'interpolated frames/sec @4K (4x4 tiles, times_to_interpolate 2)'}
 
 
 def synth_pair(h, w, seed):
@@ -110,6 +125,8 @@ def cpu_baseline(weights):
     return {
         'value': round(1.0 / (4 * dt), 6), 'unit': 'frames/s (1080p 2x2-tiled: four tiles per frame, one after the other)',
         'cores': ncores, 'kind': 'port',
+        'kind_detail': 'PyTorch-CPU (oneDNN) + numpy restatement of the TF graph (oracle/film_oracle.py) - NOT the TF2 reference, '
+                       'which is not installable here',
         'sample': f'{reps} x one 960x576 tile pair (one of the four tiles of a 1080p 2x2-tiled frame), published film_net, '
                   f'{dt:.2f} s per tile ({total:.1f} s in all) on {ncores} threads (PyTorch-CPU oneDNN convs + numpy '
                   f'warp/resize restatement, oracle/film_oracle.py); frame time = 4 tile times, nothing scaled; '
@@ -161,13 +178,34 @@ def plan_only_run(args, world, rank):
     if world > 1:
         broadcast_weights(eng, dist, src=0)
     H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
+    T = RECURSIONS.get(args.workload, 1)
     b, e = shard_range(args.pairs, world, rank)
+    stitched_ok = None
+    if args.scaling == 'strong':
+        # tile-sharded single pair: the driver, the tile ownership and the final gather on gloo, with a stand-in for the
+        # model (mean of the two tiles: tile-local like the real one) on a frame 1/8 of the workload's size
+        from film_hip.sharding import TileShardedRecursion, tiles_of_rank
+        if block is None:
+            raise SystemExit('bench.py: --scaling strong needs a tiled workload')
+        mean = lambda a, c: (a + c) * 0.5   # noqa: E731
+        g = torch.Generator().manual_seed(5)
+        f1 = torch.rand((H // 8 // block[0] * block[0], Wd // 8 // block[1] * block[1], 3), generator=g)
+        f2 = torch.rand(f1.shape, generator=g)
+        drv = TileShardedRecursion(mean, block, dist if world > 1 else None)
+        b, e = 0, len(tiles_of_rank(block, world, rank))
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
     nops = 0
     for _ in range(args.steps):
-        if e > b:
+        if args.scaling == 'strong':
+            seq = drv.run(f1, f2, T)
+            if e > b:
+                nops = len(eng.plan(e - b, tile_hw[0], tile_hw[1])['ops'])
+            if rank == 0:
+                want = TileShardedRecursion(mean, block, None).run(f1, f2, T)
+                stitched_ok = bool(torch.equal(seq, want)) and seq.shape[0] == 2 ** T + 1
+        elif e > b:
             nops = len(eng.plan(ntiles if block else (e - b), tile_hw[0], tile_hw[1])['ops'])
     dt = time.perf_counter() - t0
     reported, units = 1, e - b
@@ -189,17 +227,22 @@ def plan_only_run(args, world, rank):
         print(json.dumps({'metric': 'interpolated frames/sec @1080p', 'value': None, 'unit': 'frames/s', 'plan_only': True,
                           'n_gpus': reported, 'steps': args.steps, 'warmup': args.warmup,
                           'ms_per_step': round(dt / max(1, args.steps) * 1e3, 3), 'higher_is_better': True,
-                          'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-                          'config': {'workload': args.workload, 'pairs_sharded': units, 'plan_ops': nops,
+                          'scaling': args.scaling, 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                          'config': {'workload': args.workload, 'pairs_sharded': units if args.scaling == 'weak' else None,
+                                     'tiles_sharded': units if args.scaling == 'strong' else None,
+                                     'stitched_identical_to_one_rank': stitched_ok, 'plan_ops': nops,
                                      'weights_identical_on_all_ranks': same}}), flush=True)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=None, help='default 10 (2 for 4k_4x4_T6: a step is 1008 tile-forwards)')
+    ap.add_argument('--warmup', type=int, default=None, help='default 3 (1 for 4k_4x4_T6)')
     ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS))
+    ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
+                    help='weak (default): every rank interpolates its own frame pairs; strong: ONE pair, its tiles sharded over '
+                         'the ranks for the whole recursion tree, generated tiles gathered to rank 0 inside the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--lanes', type=int, default=1, choices=[0, 1],
@@ -214,6 +257,10 @@ def main():
     ap.add_argument('--tiny-net', action='store_true', help='with --plan-only: the small test architecture')
     ap.add_argument('--pairs', type=int, default=8, help='with --plan-only: frame pairs sharded over the ranks')
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 2 if args.workload == '4k_4x4_T6' else 10
+    if args.warmup is None:
+        args.warmup = 1 if args.workload == '4k_4x4_T6' else 3
 
     if args.gpus < 1:
         raise SystemExit('bench.py: --gpus must be >= 1')
@@ -266,24 +313,38 @@ def main():
         args.no_split = True
 
     H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
+    T = RECURSIONS.get(args.workload, 1)
+    strong = args.scaling == 'strong'
+    if strong and block is None:
+        raise SystemExit('bench.py: --scaling strong shards the tiles of one pair: it needs a tiled workload')
     pairs = ntiles if block is None else 1   # frame pairs per step (batched workloads have no tiling)
-    x0n, x1n = zip(*[synth_pair(H, Wd, 2 + rank + 17 * k) for k in range(pairs)])
+    frames_per_step = pairs * (2 ** T - 1)   # generated frames per step (per GPU when weak, per job when strong)
+    # strong scaling: every rank holds the SAME pair and owns some of its tiles; weak: every rank has its own pairs
+    x0n, x1n = zip(*[synth_pair(H, Wd, 2 + (0 if strong else rank) + 17 * k) for k in range(pairs)])
     x0 = torch.from_numpy(np.concatenate(x0n)).to(dev)
     x1 = torch.from_numpy(np.concatenate(x1n)).to(dev)
-    it = DeviceInterpolator(eng, align=align, block_shape=block)
-    if pairs > 1:
-        it = it.batch
+    dev_it = DeviceInterpolator(eng, align=align, block_shape=block)
+    it = dev_it.batch if pairs > 1 else dev_it
+    if strong:
+        from film_hip.sharding import TileShardedRecursion
+        drv = TileShardedRecursion(DeviceInterpolator(eng, align=align).batch, block, dist)
+        step = lambda: drv.run(x0[0], x1[0], T)                                      # noqa: E731
+    elif T > 1:
+        from film_hip.recursive import interpolate_pair_recursively
+        step = lambda: interpolate_pair_recursively(x0[0], x1[0], T, dev_it)             # noqa: E731
+    else:
+        step = lambda: it(x0, x1)                                                    # noqa: E731
 
     out = None
     for _ in range(args.warmup):
-        out = it(x0, x1)
+        out = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = it(x0, x1)
+        out = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -297,10 +358,26 @@ def main():
         ones = torch.ones(1, dtype=torch.float64, device=dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         reported = int(ones.item())
-    assert out is not None and bool(torch.isfinite(out).all())
+    assert (out is not None or (strong and rank != 0)) and (out is None or bool(torch.isfinite(out).all()))
 
     result = None
     if rank == 0:
+        ms_per_depth = None
+        if T > 1 and world == 1:
+            # one more recursion with a host synchronisation after every depth (depth d = 2^(d-1) pairs x the tiles)
+            frames = torch.stack([x0[0], x1[0]]).contiguous()
+            ms_per_depth = []
+            for _ in range(T):
+                torch.cuda.synchronize()
+                td = time.perf_counter()
+                mids = dev_it.batch(frames[:-1].contiguous(), frames[1:].contiguous())
+                torch.cuda.synchronize()
+                ms_per_depth.append(round((time.perf_counter() - td) * 1e3, 2))
+                nxt = torch.empty((2 * frames.shape[0] - 1,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=dev)
+                nxt[0::2] = frames
+                nxt[1::2] = mids
+                frames = nxt
+            del frames, mids, nxt
         # ---- roofline of the dominant kernel class: hipEvents around every launch, on the launch stream
         # steady state: a normal (graph) forward is queued right in front of the profiled one, with no host
         # synchronisation in between, so the first kernels are not timed on a GPU that is ramping up from idle
@@ -308,14 +385,14 @@ def main():
         eng.set_option('profile', 1)
         it(x0, x1)
         torch.cuda.synchronize()
-        prof = eng.profile()
+        prof = eng.profile()      # the LAST model invocation of that call (one chunk of tiles when the frame was chunked)
         eng.set_option('profile', 0)
         if args.profile_out:
             with open(args.profile_out, 'w') as f:
                 json.dump(prof, f)
         cls = prof['classes']
         conv = cls['conv_mfma']
-        npix = ntiles * tile_hw[0] * tile_hw[1]
+        npix = prof['B'] * prof['H'] * prof['W']      # padded input pixels of the profiled invocation
         alg_flops = CONV_FLOP_PER_PIXEL * npix
         # conv_mfma launches carry all conv FLOPs except the Cin=3 first layer and the tiny 1x1 heads
         conv_tflops = conv['flops'] / (conv['ms'] * 1e-3) / 1e12
@@ -323,6 +400,7 @@ def main():
         # FLOPs the matrix pipe really executes: the Winograd F(2,3) kernel (tile id & 256) does 2/3 of the direct
         # convolution's multiplies, the sub-pixel-folded upsample + 2x2 conv (tag ':phases') 9/16
         exec_flops = 0.0
+        dom = {'launches': 0, 'ms': 0.0, 'executed_flops': 0.0}     # the dominant kernel alone: conv_wino43_kernel
         for o in prof['ops']:
             if o['kind'] != 'conv_mfma':
                 continue
@@ -332,13 +410,18 @@ def main():
             elif o['tag'].endswith(':phases'):
                 f *= 9.0 / 16.0
             exec_flops += f
+            if (o['tile'] & 256) and (o['tile'] & 2048):
+                dom['launches'] += 1
+                dom['ms'] += o['ms']
+                dom['executed_flops'] += f
         exec_tflops = exec_flops / (conv['ms'] * 1e-3) / 1e12
-        traffic = None
-        try:  # HBM-side bytes per conv launch from the committed PMC passes of this build (profiles/)
+        traffic, traffic_src = None, None
+        try:  # fabric-side bytes per conv launch REPLAYED from the committed PMC passes of an earlier run (profiles/)
             import glob
             pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_conv.json')))
             if pmc_files and args.workload == '1080p_2x2':
                 traffic = round(json.load(open(pmc_files[-1]))['hbm_bytes_per_launch'])
+                traffic_src = os.path.relpath(pmc_files[-1], ROOT)
         except Exception:
             traffic = None
         # the roofline the conv class is priced against: the fp32 MFMA peak in the default mode; in the opt-in
@@ -355,7 +438,12 @@ def main():
                        'peak = dense bf16 MFMA peak / bf16 products per fp32 product'),
             'achieved': round(exec_tflops, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
             'frac': round(exec_tflops / peak, 4), 'traffic': traffic if not args.precision else None,
-            'traffic_note': 'bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the committed rocprofv3 PMC passes' if traffic else None,
+            'traffic_note': (f'REPLAYED, not measured in this run: bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the rocprofv3 PMC passes '
+                             f'committed in {traffic_src} (an earlier run of this kernel set; PMC needs its own rocprofv3 process)') if traffic else None,
+            'dominant_kernel': {'name': 'conv_wino43_kernel', 'launches': dom['launches'], 'ms': round(dom['ms'], 3),
+                                'executed_tflops': round(dom['executed_flops'] / max(dom['ms'], 1e-9) / 1e9, 3),
+                                'frac': round(dom['executed_flops'] / max(dom['ms'], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                                'avg_launch_ms': round(dom['ms'] / max(1, dom['launches']), 5)} if not args.precision else None,
             'launches_per_step': conv['launches'],
             'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
             'class_ms_per_step': round(conv['ms'], 3),
@@ -377,22 +465,30 @@ def main():
                 'algorithmic_bytes_per_step': cls['warp']['bytes'],
             }
         extra['kernel_ms_per_step'] = {k: round(v['ms'], 3) for k, v in cls.items()}
-        value = reported * args.steps * pairs / dt
+        value = (1 if strong else reported) * args.steps * frames_per_step / dt
         result = {
-            'metric': 'interpolated frames/sec @1080p', 'value': round(value, 4), 'unit': 'frames/s',
+            'metric': METRIC.get(args.workload, 'interpolated frames/sec @1080p'), 'value': round(value, 4), 'unit': 'frames/s',
             'n_gpus': reported, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
             'vs_baseline': None, 'dtype': 'f32' if not args.precision else ('f32 via bf16x6 exact-split MFMA (opt-in mode)' if args.precision == 1 else 'bf16x3 split MFMA, f32 accumulate (opt-in mode)'),
             'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {Wd}x{H} pair, align {align}, block_shape {block} -> '
                                    f'{ntiles} tile(s) of {tile_hw[1]}x{tile_hw[0]} in one batch, film_net published '
                                    f'config, seeded synthetic weights, t=0.5',
-                       'frames_per_step_per_gpu': pairs, 'parallelism': f'{world} independent GPU(s), weights RCCL-broadcast once',
+                       'times_to_interpolate': T, 'generated_frames_per_step': frames_per_step,
+                       'tile_forwards_per_step': frames_per_step * (ntiles if block else 1),
+                       'frames_per_step_per_gpu': None if strong else frames_per_step,
+                       'parallelism': (f'{world} GPU(s): the {ntiles} tiles of ONE pair sharded over the ranks for the whole recursion tree, '
+                                       f'one gather of the generated tiles to rank 0 per step (timed); weights RCCL-broadcast once') if strong
+                                      else f'{world} independent GPU(s), weights RCCL-broadcast once',
+                       'roofline_profiled_on': f'one model invocation of {prof["B"]} tile(s) / pair(s) of {prof["W"]}x{prof["H"]}',
                        'graph': not args.no_graph, 'lanes': args.lanes},
             'roofline': roofline,
         }
         result.update(extra)
-        if world == 1 and not args.no_split:
+        if ms_per_depth is not None:
+            result['ms_per_depth'] = ms_per_depth
+        if world == 1 and not args.no_split and T == 1:
             # Extra, NOT the headline value: the opt-in precision mode "bf16x6" (exact 3-way bf16 split of every fp32
             # operand, six partial products, fp32 accumulate) on the same workload, with its distance from the
             # default fp32-MFMA result.
@@ -410,7 +506,7 @@ def main():
                     torch.cuda.synchronize()
                     dt2 = time.perf_counter() - t1
                     result['precision_mode_' + name] = {
-                        'value': round(args.steps * pairs / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
+                        'value': round(args.steps * frames_per_step / dt2, 4), 'unit': 'frames/s', 'ms_per_step': round(dt2 / args.steps * 1e3, 3),
                         'max_abs_diff_vs_f32_mode': float((out2 - ref_out).abs().max()),
                         'note': f'opt-in (film_set_option precision={mode}: {what}, fp32 accumulate); '
                                 'the headline value above is the fp32-MFMA default',

@@ -1327,7 +1327,7 @@ uint32_t film_crc32c(uint32_t crc, const void* data, int64_t n) {
   return ~c;
 }
 
-const char* film_version(void) { return "gfx950;film_hip r2"; }
+const char* film_version(void) { return "gfx950;film_hip r3"; }
 
 int film_default_config(film_config* cfg) {
   if (!cfg) return FILM_ERR_INVALID;
@@ -1606,11 +1606,19 @@ static int groups_for_options(const film_t* h) {
 
 int film_finalize(film_t* h) {
   if (!h) return FILM_ERR_INVALID;
+  // A handle that has already run may hold cached plans whose ops point into layout groups 1..3 (F(2,3), halo, bf16
+  // copies pulled in by Planner::need_groups).  A second weight set must reach those regions too, or such a plan
+  // would mix the new group-0 layouts with the previous set's copies: re-pack everything that was packed before.
+  const int prev = h->groups_packed;
   h->groups_packed = 0;
   h->packed_floats = 0;
   h->packed_host.clear();
   h->finalized = false;
-  int rc = film_ensure_groups_(h, groups_for_options(h));
+  if (!h->plan_only && prev > 0) {   // replays of the previous weight set may still be in flight on the caller's stream
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+  }
+  int rc = film_ensure_groups_(h, std::max(groups_for_options(h), prev));
   if (rc) return rc;
   h->finalized = true;
   return FILM_OK;
@@ -1840,14 +1848,39 @@ int64_t limited_buffer_bytes(const Plan* P) {
 constexpr int64_t kMaxBufferBytes = 0xFFF00000ll;
 // One model invocation also keeps its workspace below this (a fifth of the HBM): 15 tiles of 960x576, one untiled 4K frame
 constexpr int64_t kMaxArenaBytes = 64ll << 30;
+// ... and below 60 % of the HBM this handle could get right now (free memory + what its own cached plans hold): other
+// ranks' handles, torch's allocator or a smaller part may share the device.
+int64_t arena_budget_bytes(film_t* h) {
+  int64_t cap = kMaxArenaBytes;
+  if (!h->plan_only) {
+    size_t fr = 0, tot = 0;
+    if (hipSetDevice(h->device) == hipSuccess && hipMemGetInfo(&fr, &tot) == hipSuccess) {
+      int64_t held = 0;
+      for (auto& p : h->plans) if (p->arena) held += p->arena_floats * (int64_t)sizeof(float);
+      cap = std::min<int64_t>(cap, ((int64_t)fr + held) / 10 * 6);
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return std::max<int64_t>(cap, 1);
+}
 int64_t unit_buffer_bytes(film_t* h, int H, int W, int* rc, int* max_units) {
   Plan* P1 = nullptr;
   *rc = get_plan(h, 1, H, W, false, &P1);
   if (*rc) return 0;
   const int64_t lim = limited_buffer_bytes(P1);
   const int64_t arena = std::max<int64_t>(1, P1->arena_floats * (int64_t)sizeof(float));
-  *max_units = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBufferBytes / lim, kMaxArenaBytes / arena));
+  *max_units = (int)std::max<int64_t>(1, std::min<int64_t>(kMaxBufferBytes / lim, arena_budget_bytes(h) / arena));
   return lim;
+}
+// Chunk size for n independent units with at most maxc per invocation: the largest divisor of n in (maxc / 2, maxc] if
+// there is one, so that every invocation runs the SAME cached plan (16 * 2^k tiles of a 4K recursion with maxc = 15 ->
+// chunks of 8, never a 15 + 1 split that would build, tune and capture a second plan for the remainder); else maxc.
+int balanced_chunk(int n, int maxc) {
+  if (n <= maxc) return n;
+  for (int c = maxc; 2 * c > maxc; --c)
+    if (n % c == 0) return c;
+  return maxc;
 }
 
 int forward_chunk(film_t* h, const float* x0, const float* x1, int B, int H, int W, float* out, int mem_kind, void* stream);
@@ -1870,10 +1903,13 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
                 "buffer - tile the frame (Interpolator block_shape)", H, W, unit * 1e-9);
   if (h->opt_max_batch) bmax = std::min(bmax, h->opt_max_batch);
   const size_t frame = (size_t)H * W * 3;
-  for (int b0 = 0; b0 < B; b0 += bmax) {  // independent frame pairs: the batch splits with no change in results
-    const int nb = std::min(bmax, B - b0);
+  int chunk = balanced_chunk(B, bmax);
+  for (int b0 = 0; b0 < B;) {  // independent frame pairs: the batch splits with no change in results
+    const int nb = std::min(chunk, B - b0);
     rc = forward_chunk(h, x0 + b0 * frame, x1 + b0 * frame, nb, H, W, out + b0 * frame, mem_kind, stream);
+    if (rc == FILM_ERR_NOMEM && nb > 1) { chunk = (nb + 1) / 2; continue; }   // workspace did not fit: smaller chunks (nothing was launched)
     if (rc) return rc;
+    b0 += nb;
   }
   return FILM_OK;
 }
@@ -1921,10 +1957,12 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
     HIPCHK(h, hipMemcpyAsync(st + nf, x1, frame_bytes, hipMemcpyHostToDevice, s));
     d0 = st; d1 = st + nf; dout = st + 2 * nf;
   }
-  for (int t0 = 0; t0 < ntiles; t0 += tmax) {
-    const int nt = std::min(tmax, ntiles - t0);
+  int chunk = balanced_chunk(ntiles, tmax);
+  for (int t0 = 0; t0 < ntiles;) {
+    const int nt = std::min(chunk, ntiles - t0);
     Plan* P = nullptr;
     rc = get_plan(h, nt, tp.TH, tp.TW, true, &P);
+    if (rc == FILM_ERR_NOMEM && nt > 1) { chunk = (nt + 1) / 2; continue; }   // workspace did not fit: smaller chunks
     if (rc) return rc;
     const Buffer& img0 = P->bufs[P->find("img0")];
     const Buffer& ob = P->bufs[P->find("out")];
@@ -1937,6 +1975,7 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
     if (rc) return rc;
     tp.src = P->arena + ob.off; tp.dst = dout;
     HIPCHK(h, film_launch_tiles_to_frame(tp, s));
+    t0 += nt;
   }
   if (mem_kind == FILM_MEM_HOST) {
     HIPCHK(h, hipMemcpyAsync(out, dout, frame_bytes, hipMemcpyDeviceToHost, s));
@@ -1987,8 +2026,12 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
       // the main stream; cross-lane ordering = the events found by Planner::analyze_lanes
       const size_t nops = P->ops.size();
       if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
+      hipError_t ev_err = hipSuccess;
       auto event_of = [&](size_t i) -> hipEvent_t {
-        if (!P->lane_ev[i]) (void)hipEventCreateWithFlags(&P->lane_ev[i], hipEventDisableTiming);
+        if (!P->lane_ev[i]) {
+          hipError_t e = hipEventCreateWithFlags(&P->lane_ev[i], hipEventDisableTiming);
+          if (e != hipSuccess) { ev_err = e; P->lane_ev[i] = nullptr; }
+        }
         return P->lane_ev[i];
       };
       const bool two_lanes = h->opt_lanes != 0;
@@ -2025,7 +2068,8 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
         if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
         if (le == hipSuccess && two_lanes && waited_on_last && !relay[1 - lane]) {
           hipEvent_t e = nullptr;
-          (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+          le = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+          if (le != hipSuccess) break;
           relay_pool.push_back(e);
           le = hipEventRecord(e, ls);
           relay[1 - lane] = e;
@@ -2038,6 +2082,7 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
         if (le == hipSuccess) le = hipStreamWaitEvent(h->stream, event_of(nops + 1), 0);
       }
       hipError_t ce = hipStreamEndCapture(h->stream, &P->graph);
+      if (le == hipSuccess) le = ev_err;
       if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed during capture: %s", hipGetErrorString(le));
       HIPCHK(h, ce);
       HIPCHK(h, hipGraphInstantiate(&P->graph_exec, P->graph, nullptr, nullptr, 0));

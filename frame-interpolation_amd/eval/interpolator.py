@@ -98,7 +98,7 @@ class Interpolator:
                align: Optional[int] = None,
                block_shape: Optional[List[int]] = None,
                *, device: int = 0, options: Optional[Options] = None,
-               weights=None, precision: int = 0) -> None:
+               weights=None, precision: int = 0, engine: Optional[FilmEngine] = None) -> None:
     """Loads the weights of a saved model into a HIP engine.
 
     Args:
@@ -111,13 +111,18 @@ class Interpolator:
       weights: (extension) an already loaded {name: array} dict; model_path is then ignored.
       precision: (extension) engine precision mode: 0 = fp32 MFMA (default), 1 = bf16x6, 2 = bf16x3
         (film_set_option "precision", include/film_hip.h).
+      engine: (extension) an engine that already holds its weights (a rank that received them by broadcast,
+        film_hip.sharding.sharded_interpolator); model_path and weights are then ignored.
     """
     self._options = options or PUBLISHED
-    if weights is None:
-      weights = weights_lib.load_weights(model_path, self._options)
-    weights_lib.validate_weights(weights, self._options)
-    self._engine = FilmEngine(self._options, device=device)
-    self._engine.set_weights(weights)
+    if engine is not None:
+      self._engine = engine
+    else:
+      if weights is None:
+        weights = weights_lib.load_weights(model_path, self._options)
+      weights_lib.validate_weights(weights, self._options)
+      self._engine = FilmEngine(self._options, device=device)
+      self._engine.set_weights(weights)
     if precision:
       self._engine.set_option('precision', int(precision))
     self._align = align or None

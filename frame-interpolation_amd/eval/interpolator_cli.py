@@ -10,8 +10,12 @@ DirectRunner, sorted with a natural-order key instead of natsort, mp4 via the ff
 Multi-GPU (the reference maps directories over beam workers, eval/interpolator_cli.py:180-187): under torchrun
 every rank owns one GPU (LOCAL_RANK) and a contiguous share of the work - whole directories when there are at
 least as many as ranks, otherwise consecutive input pairs of each directory (a pair's recursion tree is
-independent of every other pair; output frame indices are global, so ranks write disjoint files).  No
-collective on the data path; weights are read from --model_path on rank 0 and broadcast once (RCCL).
+independent of every other pair; output frame indices are global, so ranks write disjoint files), and for a
+directory with fewer pairs than ranks under --block_height / --block_width tiling the TILES of every pair
+(film_hip.sharding.TileShardedRecursion: rank g owns tiles_of_rank(block, world, g) for the whole recursion tree,
+one gather of the generated tiles per pair, rank 0 writes the frames - BASELINE configs[4], a 4K pair with 4x4
+tiles on 8 GPUs).  No collective on the data path; weights are read from --model_path on rank 0 and broadcast
+once (RCCL).
 
 For every directory matching --pattern: frames *.png, *.jpg, *.jpeg (each group naturally sorted, groups
 concatenated in that order, as upstream) are expanded 2^T-fold and written to
@@ -118,6 +122,44 @@ def plan_work(directories: List[str], world: int, rank: int):
     return False, out
 
 
+def tile_mode(n_pairs: int, world: int, ntiles: int) -> bool:
+    """A directory's pairs cannot occupy every rank but its tiles can: shard the tiles of each pair instead."""
+    return world > 1 and ntiles > 1 and 0 < n_pairs < world
+
+
+def process_directory_tile_sharded(directory: str, driver, args, rank: int) -> int:
+    """Every rank walks every input pair of the directory with its own tiles (driver = TileShardedRecursion bound to the
+    rank's GPU); rank 0 receives the stitched frames and writes them with the reference's naming
+    (eval/interpolator_cli.py:127-149; frame (pair p, step k) -> index p * 2^T + k, last input frame at the end)."""
+    import torch
+    inputs = list_input_frames(directory)
+    if len(inputs) < 2:
+        return 0
+    frames_dir = f'{directory}/interpolated_frames'
+    if rank == 0:
+        output_frames([], frames_dir)
+    step = 2 ** args.times_to_interpolate
+    n = 0
+    kept = []
+    for p in range(len(inputs) - 1):
+        f1, f2 = util.read_image(inputs[p]), util.read_image(inputs[p + 1])
+        seq = driver.run(driver.to_device(f1), driver.to_device(f2), args.times_to_interpolate)
+        if seq is None:
+            continue
+        seq = seq.cpu().numpy()
+        last = p == len(inputs) - 2
+        for k in range(step + (1 if last else 0)):
+            # the two ends are the input frames themselves, as the reference yields them (eval/util.py:79-80,122-123)
+            frame = f1 if k == 0 else f2 if k == step else seq[k]
+            util.write_image(f'{frames_dir}/frame_{p * step + k:03d}.png', frame)
+            if args.output_video:
+                kept.append(frame)
+            n += 1
+    if rank == 0 and args.output_video and kept:
+        write_video(f'{directory}/interpolated.mp4', kept, args.fps)
+    return n
+
+
 def process_pair_range(directory: str, first: int, end: int, n_pairs: int, it, args, clear: bool) -> int:
     """Input pairs [first, end) of a directory: frame (pair p, step k) -> frame_%03d with index p * 2^T + k; the
     rank that owns the last pair also writes the final input frame (eval/util.py:122-123)."""
@@ -153,23 +195,43 @@ def main(argv=None) -> None:
             n = process_directory(directory, it, args)
             print(f'{directory}: {n} frames')
         return
+    import datetime
     import torch
     import torch.distributed as dist
-    from film_hip.sharding import sharded_interpolator
+    from film_hip.sharding import TileShardedRecursion, sharded_interpolator
+    from film_hip.torch_io import DeviceInterpolator
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f'rank {rank} needs GPU {local_rank}, only {torch.cuda.device_count()} visible')
     torch.cuda.set_device(local_rank)
-    dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    dev = torch.device('cuda', local_rank)
+    # directories differ in size: a rank that finishes early waits at the final barrier for as long as the slowest
+    # rank works, so the collective timeout is a day, not the 10-minute default of the NCCL watchdog
+    dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev,
+                            timeout=datetime.timedelta(hours=24))
     it = sharded_interpolator(args.model_path, args.align, block, dist, local_rank, precision=args.precision)
     whole, work = plan_work(directories, world, rank)
-    # stale frames are removed by rank 0 before anybody writes (a directory's pairs may be spread over ranks)
+    ntiles = max(1, args.block_height) * max(1, args.block_width)
+    pairs_of = {d: max(0, len(list_input_frames(d)) - 1) for d in directories}
+    tiled_dirs = [] if whole else [d for d in directories if tile_mode(pairs_of[d], world, ntiles)]
+    # stale frames are removed by rank 0 before anybody writes (a directory's pairs may be spread over ranks) - only in
+    # directories that are in the work list (the single-rank path leaves directories with < 2 inputs untouched)
     if rank == 0 and not whole:
         for d in directories:
-            output_frames([], f'{d}/interpolated_frames')
+            if pairs_of[d] > 0 and d not in tiled_dirs:
+                output_frames([], f'{d}/interpolated_frames')
     dist.barrier()
+    if tiled_dirs:
+        driver = TileShardedRecursion(DeviceInterpolator(it.engine, align=it.align).batch, block, dist)
+        driver.to_device = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+        for d in tiled_dirs:     # every rank, same order: the gather inside is a collective
+            n = process_directory_tile_sharded(d, driver, args, rank)
+            print(f'[rank {rank}] {d}: tiles {driver.tiles} of {ntiles} for {pairs_of[d]} pair(s), {n} frames written')
+        it.engine.save_tune_cache()
     for directory, b, e, n_pairs in work:
+        if directory in tiled_dirs:
+            continue
         if whole:
             n = process_directory(directory, it, args)
         else:
@@ -178,6 +240,8 @@ def main(argv=None) -> None:
     dist.barrier()
     if rank == 0 and args.output_video and not whole:
         for d in directories:
+            if d in tiled_dirs:
+                continue
             files = sorted(glob.glob(f'{d}/interpolated_frames/frame_*.png'), key=natural_key)
             if files:
                 write_video(f'{d}/interpolated.mp4', [util.read_image(f) for f in files], args.fps)

@@ -81,7 +81,7 @@ def _device_driver(interpolator):
     Any other callable (e.g. the CPU oracle in tests), or FILM_HOST_RECURSION=1, gets the reference-order host
     generator above."""
     engine = getattr(interpolator, 'engine', None)
-    if engine is None or os.environ.get('FILM_HOST_RECURSION') == '1':
+    if engine is None or engine.device < 0 or os.environ.get('FILM_HOST_RECURSION') == '1':
         return None
     import torch
     from film_hip import recursive
@@ -97,6 +97,7 @@ def _device_driver(interpolator):
             a = torch.from_numpy(np.ascontiguousarray(frame1, dtype=np.float32)).to(dev)
             b = torch.from_numpy(np.ascontiguousarray(frame2, dtype=np.float32)).to(dev)
             seq = recursive.interpolate_pair_recursively(a, b, num_recursions, dev_it)[:-1].cpu().numpy()
+        engine.save_tune_cache()     # no-op unless $FILM_TUNE_CACHE is set and a new shape was measured
         if bar is not None:
             bar.update(seq.shape[0] - 1)
         yield frame1

@@ -4,6 +4,14 @@ Frame pairs (BASELINE config 4) and the tiles of a tiled frame (configs 3/5; eac
 tree depends only on that tile, eval/interpolator.py:194-206 + eval/util.py:82-91) are independent, so
 units are dealt out contiguously and the only collective is the one-time broadcast of the packed
 weight blob (RCCL over xGMI on GPUs - torch.distributed backend "nccl"; "gloo" in the CPU tests).
+
+ONE frame pair on several GPUs (configs 2 / 4: a 1080p pair has 4 tiles, a 4K pair 16): TileShardedRecursion below.
+Rank g owns the tiles tiles_of_rank(block_shape, world, g) of BOTH input frames for the whole 2^T - 1 frame recursion
+tree - the reference re-tiles every mid-frame on the same grid, so a tile of a generated frame depends on that tile of
+its two parents only - and runs the breadth-first recursion on them as a batch of small frames through the UNTILED
+entry point (per tile: pad to `align`, model, crop = exactly what the reference's tile loop does per patch,
+eval/interpolator.py:199-206).  Nothing is exchanged until the end, when the generated tiles are gathered to rank 0
+(one collective per pair, after the last model invocation) and stitched with patches_to_image's layout.
 """
 from __future__ import annotations
 
@@ -56,19 +64,120 @@ def sharded_interpolator(model_path, align, block_shape, dist, local_rank: int, 
     from eval.interpolator import Interpolator
     from .engine import FilmEngine
     from .options import PUBLISHED
-    from . import weights as W
     opt = options or PUBLISHED
     rank = dist.get_rank()
+    dev = torch.device('cuda', local_rank)
+    it, err = None, None
     if rank == 0:
-        it = Interpolator(model_path, align, block_shape, device=local_rank, options=opt, precision=precision)
-        engine = it.engine
-    else:
-        engine = FilmEngine(opt, device=local_rank)
-    broadcast_weights(engine, dist, src=0, device=torch.device('cuda', local_rank))
+        try:
+            it = Interpolator(model_path, align, block_shape, device=local_rank, options=opt, precision=precision)
+        except Exception as e:   # noqa: BLE001 - the other ranks must not be left waiting in the broadcast
+            err = e
+    ok = torch.tensor([0 if err is not None else 1], dtype=torch.int32, device=dev)
+    dist.broadcast(ok, src=0)
+    if int(ok.item()) == 0:
+        if err is not None:
+            raise err
+        raise RuntimeError('rank 0 could not load the model (see its traceback)')
+    engine = it.engine if rank == 0 else FilmEngine(opt, device=local_rank)
+    broadcast_weights(engine, dist, src=0, device=dev)
     if rank != 0:
-        it = Interpolator.__new__(Interpolator)
-        it._options, it._engine = opt, engine
-        if precision:
-            engine.set_option('precision', int(precision))
-        it._align, it._block_shape = align or None, block_shape or None
+        it = Interpolator('', align, block_shape, options=opt, precision=precision, engine=engine)
     return it
+
+# ------------------------------------------------------------------------------------------------------------------
+# one frame pair, tiles sharded over the ranks
+# ------------------------------------------------------------------------------------------------------------------
+def extract_tiles(frame, block_shape: List[int], tiles: List[int]):
+    """[H,W,3] tensor -> [len(tiles), H/bh, W/bw, 3]: the row-major tiles `tiles` of image_to_patches
+    (eval/interpolator.py:66-99; same divisibility asserts)."""
+    import torch
+    bh, bw = block_shape
+    h, w, c = frame.shape
+    ph, pw = h // bh, w // bw
+    assert h == ph * bh, 'block_height=%d should evenly divide height=%d.' % (bh, h)
+    assert w == pw * bw, 'block_width=%d should evenly divide width=%d.' % (bw, w)
+    if not tiles:
+        return torch.empty((0, ph, pw, c), dtype=frame.dtype, device=frame.device)
+    return torch.stack([frame[(t // bw) * ph:(t // bw + 1) * ph, (t % bw) * pw:(t % bw + 1) * pw] for t in tiles]).contiguous()
+
+
+def stitch_tiles(patches, block_shape: List[int]):
+    """[F, bh*bw, ph, pw, 3] -> [F, bh*ph, bw*pw, 3] (patches_to_image, eval/interpolator.py:102-126, per frame)."""
+    bh, bw = block_shape
+    f, n, ph, pw, c = patches.shape
+    assert n == bh * bw
+    return patches.reshape(f, bh, bw, ph, pw, c).permute(0, 1, 3, 2, 4, 5).reshape(f, bh * ph, bw * pw, c).contiguous()
+
+
+def recurse_tiles(t0, t1, times_to_interpolate: int, batch_fn):
+    """Breadth-first mid-point recursion (eval/util.py:62-91, one batched call per depth as film_hip/recursive.py) on a
+    set of independent tiles: t0, t1 [n, ph, pw, 3] -> [2^T + 1, n, ph, pw, 3] in temporal order (inputs included).
+    batch_fn(x0, x1) maps two [K, ph, pw, 3] batches to the K mid-frames (pad / model / crop per element)."""
+    import torch
+    frames = torch.stack([t0, t1])
+    n = t0.shape[0]
+    for _ in range(times_to_interpolate):
+        k = frames.shape[0] - 1
+        out = torch.empty((2 * k + 1,) + tuple(frames.shape[1:]), dtype=frames.dtype, device=frames.device)
+        if n:     # a rank without tiles (more ranks than tiles) only takes part in the gather
+            a = frames[:-1].reshape((k * n,) + tuple(frames.shape[2:])).contiguous()
+            b = frames[1:].reshape((k * n,) + tuple(frames.shape[2:])).contiguous()
+            out[0::2] = frames
+            out[1::2] = batch_fn(a, b).reshape((k, n) + tuple(frames.shape[2:]))
+        frames = out
+    return frames
+
+
+class TileShardedRecursion:
+    """One frame pair, T recursions, tiles of block_shape dealt over the ranks of `dist` (None = one rank).
+
+    run(frame1, frame2, T) -> on rank `dst` the [2^T + 1, H, W, 3] sequence (frame1, generated frames, frame2), None on
+    the other ranks.  batch_fn: see recurse_tiles (DeviceInterpolator(engine, align).batch on GPUs).  No collective
+    before the final gather; with one rank this is the tiled Interpolator path run tile-wise (bit-identical, test)."""
+
+    def __init__(self, batch_fn, block_shape: List[int], dist=None, dst: int = 0, collective_at_world1: bool = False):
+        self.batch_fn = batch_fn
+        self.block_shape = [int(block_shape[0]), int(block_shape[1])]
+        # collective_at_world1: tests drive the gather through the process group even when it has a single rank
+        self.dist = dist if (dist is not None and dist.is_initialized() and
+                             (dist.get_world_size() > 1 or collective_at_world1)) else None
+        self.world = self.dist.get_world_size() if self.dist else 1
+        self.rank = self.dist.get_rank() if self.dist else 0
+        self.dst = dst
+        self.ntiles = self.block_shape[0] * self.block_shape[1]
+        self.tiles = tiles_of_rank(self.block_shape, self.world, self.rank)
+        self.counts = [len(tiles_of_rank(self.block_shape, self.world, r)) for r in range(self.world)]
+
+    def local(self, frame1, frame2, times_to_interpolate: int):
+        """This rank's share: [2^T + 1, n_own, ph, pw, 3]."""
+        return recurse_tiles(extract_tiles(frame1, self.block_shape, self.tiles),
+                             extract_tiles(frame2, self.block_shape, self.tiles), times_to_interpolate, self.batch_fn)
+
+    def gather(self, local_mids):
+        """[F, n_own, ph, pw, 3] of every rank -> [F, ntiles, ph, pw, 3] on rank dst (None elsewhere).  One gather of
+        equally sized (padded to the largest share) buffers; rank r's tiles are the contiguous range shard_range gives."""
+        import torch
+        if self.dist is None:
+            return local_mids
+        nmax = max(self.counts)
+        f = local_mids.shape[0]
+        send = local_mids
+        if local_mids.shape[1] != nmax:
+            send = torch.zeros((f, nmax) + tuple(local_mids.shape[2:]), dtype=local_mids.dtype, device=local_mids.device)
+            send[:, :local_mids.shape[1]] = local_mids
+        send = send.contiguous()
+        recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == self.dst else None
+        self.dist.gather(send, recv, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        return torch.cat([recv[r][:, :self.counts[r]] for r in range(self.world) if self.counts[r]], dim=1)
+
+    def run(self, frame1, frame2, times_to_interpolate: int):
+        import torch
+        seq = self.local(frame1, frame2, times_to_interpolate)
+        mids = self.gather(seq[1:-1].contiguous())
+        if mids is None:
+            return None
+        frames = stitch_tiles(mids, self.block_shape)
+        return torch.cat([frame1[None], frames, frame2[None]], dim=0)

@@ -119,8 +119,10 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
  * align <= 0 means no padding (the reference's align=None); H, W (or the patch) must then be divisible by
  * 2^(pyramid_levels-1).  Pad / patch / crop / stitch are two HIP kernels that read the caller's frames and write
  * the plan's input buffer directly (and back), so with FILM_MEM_DEVICE nothing but the frames themselves is copied.
- * Batches are processed in chunks of tiles that keep one invocation's workspace below 64 GiB and every buffer read through a
- * 32-bit whole-buffer offset below 4 GiB (results unchanged).
+ * Batches are processed in chunks of tiles that keep one invocation's workspace below 64 GiB (and below 60 % of the HBM the
+ * handle can get at that moment) and every buffer read through a 32-bit whole-buffer offset below 4 GiB; the chunk is the
+ * largest divisor of the tile count inside that bound where one exists, so every invocation replays one cached plan
+ * (16 * 2^k tiles of a 4K recursion -> chunks of 8), and it is halved when a workspace allocation fails (results unchanged).
  * `stream` and mem_kind as for film_forward. */
 int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, int W, int align, int block_h,
                      int block_w, float* out, int mem_kind, void* stream);

@@ -117,3 +117,103 @@ def test_bench_refuses_more_gpus_than_visible():
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--plan-only'],
                          capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 2 and 'WORLD_SIZE=4' in out.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one frame pair, tiles sharded over the ranks (film_hip.sharding.TileShardedRecursion) - SURVEY 8(e)
+# ---------------------------------------------------------------------------------------------------------------------
+_TS_H, _TS_W, _TS_BLOCK, _TS_T, _TS_ALIGN = 44, 56, [2, 2], 2, 8     # tiles of 22x28, each padded to 24x32
+
+
+def _oracle_batch_fn(weights):
+    """batch_fn of the driver with the CPU oracle (TINY net) as the model: per element pad to align, forward, crop -
+    Interpolator.interpolate (eval/interpolator.py:152-176), what the reference's tile loop calls per patch."""
+    from conftest import oracle_options
+    from film_hip.options import TINY
+    from oracle import film_oracle as fo
+    it = fo.OracleInterpolator(weights, align=_TS_ALIGN, block_shape=None, opt=oracle_options(TINY))
+    dt = np.full((1,), 0.5, np.float32)
+
+    def fn(a, b):
+        out = [it.interpolate(a[i:i + 1].numpy(), b[i:i + 1].numpy(), dt) for i in range(a.shape[0])]
+        return torch.from_numpy(np.concatenate(out, axis=0))
+    return fn
+
+
+def _tile_worker(rank, world, port, q):
+    import sys
+    for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    from film_hip.sharding import TileShardedRecursion
+    import inputs
+    x0, x1 = inputs.frame_pair(1, _TS_H, _TS_W, seed=23)
+    drv = TileShardedRecursion(_oracle_batch_fn(W.make_synthetic_weights(TINY, seed=0)), _TS_BLOCK, dist)
+    seq = drv.run(torch.from_numpy(x0[0]), torch.from_numpy(x1[0]), _TS_T)
+    q.put((rank, drv.tiles, None if seq is None else seq.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_tile_sharded_pair_world_n_gloo(world, tiny_weights):
+    """ONE frame pair, its 2x2 tiles dealt over `world` gloo ranks for the whole T = 2 recursion tree: the tile sets are
+    disjoint and complete (world 3: shares of 2, 1, 1 - the padded gather), only rank 0 gets frames, and they are
+    byte-identical to (a) the same driver on one rank and (b) the REFERENCE-ORDER depth-first recursion
+    (eval/util.py:62-91) over the tiled OracleInterpolator (eval/interpolator.py:192-206)."""
+    import inputs
+    from conftest import oracle_options
+    from eval import util
+    from film_hip.options import TINY
+    from film_hip.sharding import TileShardedRecursion
+    from oracle import film_oracle as fo
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    tiles = [t for _, ts, _ in res for t in ts]
+    assert tiles == [0, 1, 2, 3]
+    assert all(seq is None for r, _, seq in res if r != 0)
+    got = res[0][2]
+    assert got.shape == (2 ** _TS_T + 1, _TS_H, _TS_W, 3)
+    x0, x1 = inputs.frame_pair(1, _TS_H, _TS_W, seed=23)
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(2)      # as the workers: oneDNN's blocking (and with it the fp32 rounding) follows the thread count
+    one = TileShardedRecursion(_oracle_batch_fn(tiny_weights), _TS_BLOCK, None).run(
+        torch.from_numpy(x0[0]), torch.from_numpy(x1[0]), _TS_T).numpy()
+    assert np.abs(got - one).max() < 1e-5, np.abs(got - one).max()
+    assert np.array_equal(got, one)
+    it = fo.OracleInterpolator(tiny_weights, align=_TS_ALIGN, block_shape=_TS_BLOCK, opt=oracle_options(TINY))
+    want = list(util._recursive_generator(x0[0], x1[0], _TS_T, it)) + [x1[0]]
+    torch.set_num_threads(nthreads)
+    assert np.array_equal(got, np.stack(want))
+
+
+def test_bench_strong_scaling_launcher_world2_plan_only():
+    """`python bench.py --gpus 2 --scaling strong` on CPU (gloo, plan-only engines): the tiles of ONE pair sharded over
+    two ranks through the real driver + gather, stitched result identical to one rank, "scaling": "strong" in the line."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--plan-only', '--tiny-net', '--steps', '1',
+                          '--warmup', '0', '--scaling', 'strong', '--workload', '1080p_2x2_T3'],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['config']['tiles_sharded'] == 4
+    assert r['config']['stitched_identical_to_one_rank'] is True and r['config']['weights_identical_on_all_ranks'] is True

@@ -1,0 +1,283 @@
+"""Round-3 GPU tests: BASELINE configs[4] (4K, 4x4 tiles, times_to_interpolate 6) recursion depth, the tile-sharded
+single-pair driver, the N-rank start-up helper on RCCL, a second weight set on a used engine, the SavedModel
+directory path of Interpolator, and parity where F(4,3) round-off and the warp clamps bite: trained-net-like dynamic range
+and flows that leave the frame at every level, each against the float32 AND the float64 oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import inputs as TI
+from test_gpu_parity import _engine
+
+pytestmark = pytest.mark.gpu
+
+IMAGE_TOL = 1e-3          # north_star: |delta| < 1e-3 fp32 per pixel
+HALF = np.full((1,), 0.5, np.float32)
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module')
+def published():
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    eng = _engine(PUBLISHED, w)
+    yield PUBLISHED, w, eng
+    eng.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[4]: depth-6 recursion
+# ---------------------------------------------------------------------------------------------------------------------
+def test_depth6_recursion_of_one_4k_tile_against_the_oracle_tree(published):
+    """One tile's WHOLE times_to_interpolate = 6 recursion tree of the 4K 4x4-tiled pair (63 tile-forwards of 960x540 padded
+    to 960x576; eval/util.py:62-91 over eval/interpolator.py:192-206) on the default fp32 plan, against the committed
+    oracle fixture (tools/make_t6_golden.py: stride-12 sample + float64 row / column sums of every generated frame).
+    Round-off is fed back six times: max|delta| is printed per generation and the sixth must stay < 1e-3."""
+    import torch
+    from film_hip.sharding import extract_tiles, recurse_tiles
+    from film_hip.torch_io import DeviceInterpolator
+    path = os.path.join(GOLDEN, 'oracle_t6_tile.npz')
+    if not os.path.isfile(path):
+        pytest.skip('tests/golden/oracle_t6_tile.npz not generated yet (python tools/make_t6_golden.py)')
+    g = np.load(path)
+    opt, w, eng = published
+    x0, x1 = TI.frame_pair(1, 2160, 3840, seed=4)
+    block, tile, stride = [int(v) for v in g['block']], int(g['tile']), int(g['stride'])
+    dev = torch.device('cuda', 0)
+    a = extract_tiles(torch.from_numpy(x0[0]), block, [tile]).to(dev)
+    b = extract_tiles(torch.from_numpy(x1[0]), block, [tile]).to(dev)
+    assert np.allclose([float(a.double().sum()), float(b.double().sum())], g['in_checksum'], rtol=0, atol=1e-6)
+    T = int(np.log2(len(g['frame_index']) + 1))
+    seq = recurse_tiles(a, b, T, DeviceInterpolator(eng, align=64).batch)[:, 0].cpu().numpy()     # [2^T + 1, 540, 960, 3]
+    assert seq.shape[0] == 2 ** T + 1 and np.isfinite(seq).all()
+    per_depth = {}
+    for i, (k, d) in enumerate(zip(g['frame_index'], g['depth'])):
+        f = seq[int(k)]
+        ds = float(np.abs(f[::stride, ::stride] - g['sample'][i]).max())
+        dr = float(np.abs(f.astype(np.float64).sum(axis=1) - g['rowsum'][i]).max() / f.shape[1])
+        dc = float(np.abs(f.astype(np.float64).sum(axis=0) - g['colsum'][i]).max() / f.shape[0])
+        per_depth[int(d)] = max(per_depth.get(int(d), 0.0), ds, dr, dc)
+    line = ', '.join(f'gen {d}: {per_depth[d]:.2e}' for d in sorted(per_depth))
+    growth = [per_depth[d + 1] / max(per_depth[d], 1e-12) for d in sorted(per_depth)[:-1]]
+    print(f'T = {T} recursion of tile {tile}: hip vs oracle max|d| per generation: {line}; growth per generation '
+          f'{[round(x, 2) for x in growth]}')
+    assert per_depth[T] < IMAGE_TOL and max(per_depth.values()) < IMAGE_TOL
+
+
+def test_4k_4x4_chunks_replay_one_plan(published):
+    """A 4K pair with 4x4 tiles = 16 tiles of 960x576 against a 15-tile invocation limit: the chunks are 8 + 8 (one cached
+    plan), not 15 + 1, and the frame equals the one computed with at most 4 tiles per invocation bit for bit."""
+    import torch
+    from film_hip.torch_io import DeviceInterpolator
+    opt, w, eng = published
+    x0, x1 = TI.frame_pair(1, 2160, 3840, seed=4)
+    dev = torch.device('cuda', 0)
+    a, b = torch.from_numpy(x0).to(dev), torch.from_numpy(x1).to(dev)
+    it = DeviceInterpolator(eng, align=64, block_shape=[4, 4])
+    full = it(a, b)
+    torch.cuda.synchronize()
+    eng.set_option('profile', 1)
+    it(a, b)
+    torch.cuda.synchronize()
+    prof = eng.profile()
+    eng.set_option('profile', 0)
+    assert prof['B'] in (8, 16), prof['B']           # never a 1-tile remainder plan
+    eng.set_option('max_batch', 4)
+    small = it(a, b)
+    torch.cuda.synchronize()
+    eng.set_option('max_batch', 0)
+    assert torch.equal(full, small) and bool(torch.isfinite(full).all())
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# tile-sharded single pair + the N-rank start-up on RCCL (world size 1 is what one GPU allows)
+# ---------------------------------------------------------------------------------------------------------------------
+def test_tile_sharded_driver_is_bit_identical_to_the_tiled_path(published):
+    """TileShardedRecursion on one rank (tiles run through the UNTILED entry point as a batch of small frames, stitched at
+    the end) vs the tiled breadth-first driver (film_interpolate with block_shape): same frames, same bits, T = 2."""
+    import torch
+    from film_hip.recursive import interpolate_pair_recursively
+    from film_hip.sharding import TileShardedRecursion
+    from film_hip.torch_io import DeviceInterpolator
+    opt, w, eng = published
+    x0, x1 = TI.frame_pair(1, 200, 336, seed=12)
+    dev = torch.device('cuda', 0)
+    a, b = torch.from_numpy(x0[0]).to(dev), torch.from_numpy(x1[0]).to(dev)
+    want = interpolate_pair_recursively(a, b, 2, DeviceInterpolator(eng, align=64, block_shape=[2, 2]))
+    got = TileShardedRecursion(DeviceInterpolator(eng, align=64).batch, [2, 2], None).run(a, b, 2)
+    assert got.shape == want.shape == (5, 200, 336, 3)
+    assert torch.equal(got, want)
+
+
+def test_sharded_interpolator_and_tile_gather_over_rccl(published, tmp_path):
+    """film_hip.sharding.sharded_interpolator (rank 0 loads the model directory, status + weight broadcast over the nccl =
+    RCCL backend) and the tile gather of TileShardedRecursion through the same process group, on the one GPU there is
+    (world_size 1, collective forced): result bit-identical to the plain tiled Interpolator of the module's engine."""
+    import torch
+    import torch.distributed as dist
+    from film_hip import weights as W
+    from film_hip.sharding import TileShardedRecursion, sharded_interpolator
+    from film_hip.torch_io import DeviceInterpolator
+    opt, w, eng = published
+    W.save_weights(str(tmp_path / 'model'), w)
+    with socket.socket() as so:
+        so.bind(('127.0.0.1', 0))
+        port = so.getsockname()[1]
+    os.environ['MASTER_ADDR'], os.environ['MASTER_PORT'] = '127.0.0.1', str(port)
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
+    try:
+        it = sharded_interpolator(str(tmp_path / 'model'), 64, [2, 2], dist, 0)
+        assert it.align == 64 and it.block_shape == [2, 2]
+        x0, x1 = TI.frame_pair(1, 200, 336, seed=12)
+        want = DeviceInterpolator(eng, align=64, block_shape=[2, 2])(torch.from_numpy(x0).to(dev), torch.from_numpy(x1).to(dev))
+        assert np.array_equal(it(x0, x1, HALF), want.cpu().numpy())
+        drv = TileShardedRecursion(DeviceInterpolator(it.engine, align=64).batch, [2, 2], dist, collective_at_world1=True)
+        assert drv.dist is not None and drv.tiles == [0, 1, 2, 3]
+        seq = drv.run(torch.from_numpy(x0[0]).to(dev), torch.from_numpy(x1[0]).to(dev), 1)
+        assert seq.shape == (3, 200, 336, 3) and torch.equal(seq[1], want[0])
+        with pytest.raises(Exception):        # a model directory rank 0 cannot load must raise, not hang the other ranks
+            sharded_interpolator(str(tmp_path / 'missing'), 64, [2, 2], dist, 0)
+        it.engine.close()
+    finally:
+        dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# weights: second set on a used engine, SavedModel directory
+# ---------------------------------------------------------------------------------------------------------------------
+def test_second_weight_set_on_a_used_engine(tiny_weights):
+    """forward -> set_weights(other set) -> forward of the SAME shape on the SAME handle (cached plan, layout groups the
+    plan pulled in on demand) == a fresh engine that only ever saw the second set (round-2 ADVICE: the re-finalize used
+    to repack group 0 only)."""
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    w2 = W.make_synthetic_weights(TINY, seed=11)
+    x0, x1 = TI.frame_pair(1, 128, 96, seed=3)
+    eng = _engine(TINY, tiny_weights)
+    for key, val in (('winograd', 0), ('winograd', 2), ('winograd', 1)):    # plans on the halo / F(2,3) / default families
+        eng.set_option(key, val)
+        first = eng.forward(x0, x1)
+        eng.set_weights(w2)
+        second = eng.forward(x0, x1)
+        fresh = _engine(TINY, w2)
+        fresh.set_option(key, val)
+        want = fresh.forward(x0, x1)
+        fresh.close()
+        assert np.array_equal(second, want) and not np.array_equal(first, second), (key, val)
+        eng.set_weights(tiny_weights)
+    eng.close()
+
+
+def test_interpolator_from_a_savedmodel_directory(published, tmp_path):
+    """Interpolator(model_path=<SavedModel dir>) - variables bundle written with the object-graph keys of a Keras
+    model.save() (film_hip.tf_bundle.save_film_bundle), read back by the TF-free reader - gives the bits of the engine
+    that took the same tensors as a dict."""
+    from eval.interpolator import Interpolator
+    from film_hip import tf_bundle
+    opt, w, eng = published
+    tf_bundle.save_film_bundle(str(tmp_path / 'saved_model'), w, opt)
+    assert os.path.isfile(tmp_path / 'saved_model' / 'variables' / 'variables.index')
+    it = Interpolator(str(tmp_path / 'saved_model'), align=64)
+    x0, x1 = TI.frame_pair(1, 120, 200, seed=6)
+    got = it(x0, x1, HALF)
+    want = eng.interpolate_frames(x0, x1, align=64)
+    assert np.array_equal(got, want)
+    it.engine.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# parity hardening: dynamic range and large motion, default plan, vs float32 AND float64 oracle
+# ---------------------------------------------------------------------------------------------------------------------
+def _f64(weights):
+    return {k: v.astype(np.float64) for k, v in weights.items()}
+
+
+def _rescaled_weights(w, opt, s):
+    """Trained-net-like dynamic range: the sub-extractor's first layer (kernel and bias) is scaled by s - leaky_relu is
+    positively homogeneous, so every feature map grows by about s - and the layers that CONSUME features (flow-predictor
+    conv_0, the feature rows of fusion/convs_i_1 and of the coarsest 2x2 layer) are scaled by 1 / s, so flows and the image
+    stay O(1) while every convolution of the extractor and every warp works on activations of size s."""
+    from film_hip import weights as W
+    out = {k: v.copy() for k, v in w.items()}
+    out['feat_net/sub_extractor/cfeat_conv_0/kernel'] *= np.float32(s)
+    out['feat_net/sub_extractor/cfeat_conv_0/bias'] *= np.float32(s)
+    for k in out:
+        if k.startswith('predict_flow') and k.endswith('conv_0/kernel'):
+            out[k] /= np.float32(s)
+    fc = W.feature_channels(opt)
+    L = opt.fusion_pyramid_levels
+    for i in range(L - 1):
+        k1 = out[f'fusion/convs_{i}_1/kernel']                 # input order [img0 3 | feat0 C | img1 3 | feat1 C | flows 4 | net]
+        c = fc[i]
+        k1[:, :, 3:3 + c] /= np.float32(s)
+        k1[:, :, 6 + c:6 + 2 * c] /= np.float32(s)
+    c = fc[L - 1]
+    k0 = out[f'fusion/convs_{L - 2}_0/kernel']
+    k0[:, :, 3:3 + c] /= np.float32(s)
+    k0[:, :, 6 + c:6 + 2 * c] /= np.float32(s)
+    return out
+
+
+@pytest.mark.parametrize('scale', [100.0, 1000.0])
+def test_parity_with_trained_net_like_dynamic_range(scale):
+    """Feature activations of 10^2 / 10^3 (F(4,3)'s round-off is relative to the activation magnitude): default plan on a
+    256x320 pair vs the float32 and the float64 oracle."""
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    from oracle import film_oracle as fo
+    w = _rescaled_weights(W.make_synthetic_weights(PUBLISHED, seed=0), PUBLISHED, scale)
+    x0, x1 = TI.frame_pair(1, 256, 320, seed=9)
+    eng = _engine(PUBLISHED, w)
+    got = eng.forward(x0, x1)
+    feat_max = float(np.abs(eng.tap('feat0')).max())
+    eng.close()
+    o32, aux = fo.film_forward(x0, x1, w, fo.Options(), return_aux=True)
+    o64 = fo.film_forward(x0.astype(np.float64), x1.astype(np.float64), _f64(w), fo.Options())
+    e_hip32, e_hip64, e_or = (float(np.abs(got - o32).max()), float(np.abs(got - o64).max()), float(np.abs(o32 - o64).max()))
+    flow0 = float(np.abs(aux['forward_flow_pyramid'][0]).max())
+    print(f'scale {scale:g}: |feat0| max {feat_max:.1f}, |flow0| max {flow0:.1f} px, |image| max {np.abs(o64).max():.2f}; '
+          f'hip vs f32 oracle {e_hip32:.2e}, hip vs f64 oracle {e_hip64:.2e}, f32 oracle vs f64 {e_or:.2e} '
+          f'(ratio {e_hip64 / max(e_or, 1e-12):.1f})')
+    assert feat_max > 0.5 * scale
+    assert e_hip64 < IMAGE_TOL and e_hip32 < IMAGE_TOL
+    assert e_hip64 <= max(8 * e_or, 2e-5), 'the HIP plan loses much more to round-off than the fp32 oracle itself'
+
+
+def test_parity_with_flows_that_leave_the_frame_at_every_level():
+    """Flow heads scaled until the level-0 flows exceed +-32 px (FILM exists for large motion): every warped level samples
+    outside the frame (the clamps of util.py:48-82 / dense_image_warp) and a flow error doubles per level
+    (pyramid_flow_estimator.py:151-161).  Default plan vs the float32 and the float64 oracle."""
+    from film_hip import weights as W
+    from film_hip.options import PUBLISHED
+    from oracle import film_oracle as fo
+    w = W.make_synthetic_weights(PUBLISHED, seed=0)
+    for k in list(w):
+        if k.startswith('predict_flow') and ('conv_4/' in k):
+            w[k] = w[k] * np.float32(8.0)
+    x0, x1 = TI.frame_pair(1, 256, 320, seed=10, shift=(15, -21), fg_shift=(-12, 25))
+    eng = _engine(PUBLISHED, w)
+    got = eng.forward(x0, x1)
+    v0 = eng.tap('v0')
+    eng.close()
+    o32, aux = fo.film_forward(x0, x1, w, fo.Options(), return_aux=True)
+    o64, aux64 = fo.film_forward(x0.astype(np.float64), x1.astype(np.float64), _f64(w), fo.Options(), return_aux=True)
+    outside = []
+    for l, f in enumerate(aux64['forward_flow_pyramid']):
+        h, wd = f.shape[1:3]
+        yy, xx = np.mgrid[0:h, 0:wd]
+        qx, qy = xx + 0.5 * f[0, ..., 0], yy + 0.5 * f[0, ..., 1]
+        outside.append(float(((qx < 0) | (qx > wd - 1) | (qy < 0) | (qy > h - 1)).mean()))
+    fmax = float(np.abs(aux64['forward_flow_pyramid'][0]).max())
+    e_flow_hip = float(np.abs(v0[:1] - aux64['forward_flow_pyramid'][0]).max())
+    e_flow_or = float(np.abs(aux['forward_flow_pyramid'][0] - aux64['forward_flow_pyramid'][0]).max())
+    e_hip32, e_hip64, e_or = (float(np.abs(got - o32).max()), float(np.abs(got - o64).max()), float(np.abs(o32 - o64).max()))
+    print(f'large motion: |flow0| max {fmax:.1f} px, share of t=0.5 samples outside the frame per level {[round(o, 3) for o in outside]}; '
+          f'flow0 error hip {e_flow_hip:.2e} px / f32 oracle {e_flow_or:.2e} px vs f64; image: hip vs f32 oracle {e_hip32:.2e}, '
+          f'hip vs f64 {e_hip64:.2e}, f32 oracle vs f64 {e_or:.2e} (ratio {e_hip64 / max(e_or, 1e-12):.1f})')
+    assert fmax > 32.0 and min(outside) > 0.0
+    assert e_hip64 < IMAGE_TOL and e_hip32 < IMAGE_TOL
+    assert e_hip64 <= max(8 * e_or, 2e-5)

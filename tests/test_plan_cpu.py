@@ -393,3 +393,30 @@ def test_tune_cache_text_round_trip_and_validation(tiny_weights):
         with pytest.raises(FilmError):
             eng.import_tune(bad)
     eng.close()
+
+
+def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_weights):
+    """A handle whose cached plans pulled in the on-demand layout groups (Planner::need_groups: F(2,3), halo copies) gets a
+    SECOND weight set (film_finalize via set_weights / film_import_packed): every group that was packed before must be packed
+    again from the new tensors - the cached plan's ops keep pointing into those regions - so the layout blob has the same
+    extent and the same bytes as a fresh handle that took the new set first and then built the same plan (round-2 ADVICE)."""
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    w2 = W.make_synthetic_weights(TINY, seed=11)
+    eng = FilmEngine(TINY, device=-1)
+    eng.set_weights(tiny_weights)
+    base = eng.export_layouts().size
+    kinds = {(op['halo'], op['wino']) for op in eng.plan(1, 128, 96)['ops'] if op['kind'] == 'conv_mfma'}
+    grown = eng.export_layouts().size
+    assert grown > base, ('the test needs a plan that reads an on-demand layout group', kinds)
+    eng.import_packed(eng.export_packed())              # same weights again: extent and bytes unchanged
+    assert eng.export_layouts().size == grown
+    before = eng.export_layouts().copy()
+    eng.set_weights(w2)                                 # different weights on the used handle
+    after = eng.export_layouts()
+    assert after.size == grown and not np.array_equal(after, before)
+    fresh = FilmEngine(TINY, device=-1)
+    fresh.set_weights(w2)
+    fresh.plan(1, 128, 96)
+    assert np.array_equal(after, fresh.export_layouts())
