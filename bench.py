@@ -245,9 +245,10 @@ def main():
                          'the ranks for the whole recursion tree, generated tiles gathered to rank 0 inside the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true')
-    ap.add_argument('--lanes', type=int, default=1, choices=[0, 1],
+    ap.add_argument('--lanes', type=int, default=1, choices=[0, 1, 2],
                     help='0: replay the graph on ONE stream (serialised kernels: what the committed rocprofv3 kernel trace uses, '
-                         'so that per-kernel durations are not inflated by overlap); 1 (default): two-stream graph')
+                         'so that per-kernel durations are not inflated by overlap); 1: two-stream graph, decoder behind the flow '
+                         'estimator (default); 2: coarse decoder levels on the side stream beside the estimator (measured slower)')
     ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
                     help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
     ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
@@ -306,8 +307,8 @@ def main():
         eng.set_option('tune_ms', int(os.environ['FILM_TUNE_MS']))
     if args.no_graph:
         eng.set_option('graph', 0)
-    if not args.lanes:
-        eng.set_option('lanes', 0)
+    if args.lanes != 1:
+        eng.set_option('lanes', args.lanes)
     if args.precision:
         eng.set_option('precision', args.precision)
         args.no_split = True

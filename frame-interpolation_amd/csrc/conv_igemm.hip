@@ -116,6 +116,11 @@ static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
     case W43_Q16_4x32_T11_P2: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_PF2, 16>(p, s);
     case W43_Q16_4x64_N1_P2: return conv_wino43_launch<4, 64, 1, 1, F | W43_F_PF2, 16, 1>(p, s);
     case W43_Q16_4x32_T11_BG: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_BG, 16>(p, s);
+    case W43_Q8_8x64_T21_P2: return conv_wino43_launch<8, 64, 2, 1, F | W43_F_PF2, 8>(p, s);
+    case W43_Q8_8x64_T12_P2: return conv_wino43_launch<8, 64, 1, 2, F | W43_F_PF2, 8>(p, s);
+    case W43_Q8_8x64_N1_P2: return conv_wino43_launch<8, 64, 1, 1, F | W43_F_PF2, 8, 1>(p, s);
+    case W43_Q8_8x32_T11_BG: return conv_wino43_launch<8, 32, 1, 1, F | W43_F_BG, 8>(p, s);
+    case W43_Q8_8x32_T11_P2: return conv_wino43_launch<8, 32, 1, 1, F | W43_F_PF2, 8>(p, s);
     default: return hipErrorInvalidValue;
   }
 }
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 }
 
 static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream_t s) {
-  const int shape = tile & (CONV_TILE_XCD - 1);
+  const int shape = (tile & (CONV_TILE_XCD - 1)) + (((tile & CONV_TILE_EXT) && (tile & CONV_TILE_F43)) ? 16 : 0);
   if ((p.pool_out != nullptr || p.pw_out != nullptr) && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
   if (tile & CONV_TILE_FOLDX3) {
     if (p.ksize != 2 || p.fold != 2) return hipErrorInvalidValue;
@@ -177,7 +182,7 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
     if (p.ksize != 3) return hipErrorInvalidValue;
     if (tile & CONV_TILE_X3) return (tile & CONV_TILE_XCD) ? launch_winox3<CONV_B_XCD_M>(p, shape, s) : launch_winox3<0>(p, shape, s);
     if ((tile & CONV_TILE_F43) && p.pool_out != nullptr && shape < W43_Q16_4x64_T21) return hipErrorInvalidValue;   // fused pool: 64-pixel tiles only
-    if (p.pw_out != nullptr && (!(tile & CONV_TILE_F43) || (shape != W43_Q16_4x64_N1 && shape != W43_Q16_4x64_N1_P2) || p.Cout != 64 || p.ksplit > 1 ||
+    if (p.pw_out != nullptr && (!(tile & CONV_TILE_F43) || (shape != W43_Q16_4x64_N1 && shape != W43_Q16_4x64_N1_P2 && shape != W43_Q8_8x64_N1_P2) || p.Cout != 64 || p.ksplit > 1 ||
                                 p.pool_out != nullptr || p.pw_cout < 1 || p.pw_cout > 4))
       return hipErrorInvalidValue;   // fused 1x1: a workgroup must hold all 64 channels of its pixels in one wave set
     if (tile & CONV_TILE_F43) return (tile & CONV_TILE_XCD) ? launch_wino43<CONV_B_XCD_M>(p, shape, s) : launch_wino43<0>(p, shape, s);

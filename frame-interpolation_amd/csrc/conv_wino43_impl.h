@@ -15,9 +15,12 @@
 // fp32 throughout; on a K = 4608 test sum the rounding error is 3.9e-6 relative (F(2,3): 8.6e-7, direct: 6.4e-7).
 //
 //   * a workgroup owns TH rows x 4*QW pixels x BN output channels; QW = quads per patch row: 32 (128 pixels, one 32-row
-//     MFMA tile per patch row) or 16 (64 pixels, one MFMA tile per TWO patch rows: lanes 0-15 row r, 16-31 row r+1).
-//     The QW = 16 tiles are 4-wave workgroups with 72 KB of LDS: TWO per CU, whose barriers / fragment waits / epilogues
-//     are not in phase, and twice as many (half-size) workgroups per layer for the tails of the 120-wide level;
+//     MFMA tile per patch row), 16 (64 pixels, one MFMA tile per TWO patch rows: lanes 0-15 row r, 16-31 row r+1) or
+//     8 (32 pixels, one MFMA tile per FOUR patch rows).  The QW = 16 tiles are 4-wave workgroups with 72 KB of LDS: TWO
+//     per CU, whose barriers / fragment waits / epilogues are not in phase, and twice as many (half-size) workgroups per
+//     layer for the tails of the 120-wide level.  The QW = 8 tiles (TH = 8: the same 256 pixels per workgroup, 66 KB) fit
+//     the 15 * 2^k wide pyramid levels of a 960-wide tile exactly (480 = 15 x 32: no empty quads, where 64-pixel patches
+//     leave 6.25 % of every patch row empty) and stage 10 halo rows per 8 output rows instead of 6 per 4;
 //   * K chunks of 8 channels; the (TH+2) halo rows of a chunk are transformed ONCE on the way into LDS, image
 //     [halo row][nu 6][quad QW][8 channels] (32-byte rows, K-halves swapped on bit 3 of the quad: conflict-free b128);
 //   * the six nu planes are independent GEMMs.  NH = 2: wave half h accumulates nu = 3h .. 3h+2 for its TM rows x TN channel
@@ -40,12 +43,16 @@ enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priori
        W43_DBG_NOALOAD = 4096, // activation loads skipped, transform + LDS stores of stale registers kept
        W43_DBG_NOASTORE = 8192,// activation loads kept, transform + LDS stores skipped
        W43_F_PF2 = 32768,      // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
+       W43_F_PERSIST = 524288, // the pair loop exists (ConvParams::persist launches need it; without it a workgroup runs ONE pair and the
+                               // code is the straight-line kernel: the loop costs the 128-register tile its four workgroups per CU)
+       W43_F_PRE1 = 131072,    // persistent launches: the next pair's first activation chunk is requested in front of the epilogue
+       W43_F_PRE2 = 262144,    // ... and so is the rest of its prologue (weight stages, PF2's second chunk): 84 more live registers
        W43_F_BG = 65536 };     // weight fragments straight from global memory (L1 / L2) into registers, requested two stages
                                // ahead: no weight ring in LDS (36 KB instead of 54 KB for the 32-channel tile = FOUR workgroups
                                // per CU), no weight stores, two barriers per chunk instead of three
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
-__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & W43_F_BG) != 0 && BN == 32 && QW == 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
+__global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & W43_F_BG) != 0 && BN == 32 && QW <= 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
   constexpr int RPT = 32 / QW;                 // patch rows per 32-quad MFMA tile
   constexpr int MT = TH / RPT;                 // MFMA row tiles per patch; TM of them per wave
   constexpr int NU = 6 / NH;                   // nu planes per wave
@@ -60,7 +67,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   constexpr int BU = BN * 12;                  // float4 units of one weight stage
   constexpr int BLD = (BU + NT - 1) / NT;
   constexpr int PXW = 4 * QW;                  // patch width in pixels
-  static_assert(QW == 32 || QW == 16, "quads per patch row");
+  static_assert(QW == 32 || QW == 16 || QW == 8, "quads per patch row");
   static_assert(TH % RPT == 0 && MT % TM == 0 && BN % (32 * TN) == 0 && ITEMS <= NT && 2 * ITEMS > NT, "bad tile");
   constexpr bool BG = (FLAGS & W43_F_BG) != 0;
   static_assert(NH == 1 || 2 * PW * TM * TN * 16 * 64 <= 2 * A_STAGE + (BG ? 0 : 3 * B_STAGE), "exchange buffer does not fit");
@@ -76,35 +83,56 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   const int h = wv / PW, pw = wv % PW;     // nu half, pair-wave
   const int rg = pw / NG, ng = pw % NG;
 
-  int bx = blockIdx.x, by = blockIdx.y;
-  if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
-    const int nbx = gridDim.x, nby = gridDim.y;
-    const int nwg = nbx * nby;
-    const int lin = by * nbx + bx;
-    const int xcd = lin & 7, idx = lin >> 3;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    const int nl = base + idx;
-    bx = nl / nby;
-    by = nl - bx * nby;
-  }
+  // ---- the (patch, channel block) pairs of this workgroup: lin, lin + stride, ... of the NB * ntx * nty * (Cout / BN) pairs.
+  // A launch with one workgroup per pair has stride == total (the loop at the bottom runs once); a PERSISTENT launch
+  // (ConvParams::persist workgroups per K split, grid.y = 1) walks several per workgroup and requests the first loads of
+  // the next pair IN FRONT OF the epilogue of the current one, so that the fixed cost of a pair - three K chunks' worth of
+  // load latency, exchange and 64 KB of stores - overlaps inside the workgroup as well as across the workgroups of a CU.
   const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
-  const int img = bx / (ntx * nty);
-  const int trem = bx - img * (ntx * nty);
-  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * PXW;
-  const int n0 = by * BN;
+  const int nbx = p.NB * ntx * nty, nby = p.Cout / BN;
+  const int total = nbx * nby;
+  const int stride = (int)(gridDim.x * gridDim.y);
+  int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  int img = 0, y0 = 0, x0 = 0, n0 = 0;
+  auto decode = [&](int l) {
+    int bx, by;
+    if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {   // pairs dealt to the eight XCDs as eight contiguous runs
+      const int xcd = l & 7, idx = l >> 3;
+      const int q = total >> 3, r = total & 7;
+      const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+      const int nl = base + idx;
+      bx = nl / nby;
+      by = nl - bx * nby;
+    } else {
+      by = l / nbx;
+      bx = l - by * nbx;
+    }
+    img = bx / (ntx * nty);
+    const int trem = bx - img * (ntx * nty);
+    y0 = (trem / ntx) * TH;
+    x0 = (trem % ntx) * PXW;
+    n0 = by * BN;
+  };
+  decode(lin);
 
   // ---- the A staging item of this thread: (halo row hy, quad tq, channel group q); threads past the last item repeat
   // one (same values to the same LDS address) so that the staging code has no divergent branch -------------------------
   int f = t;
   if (f >= ITEMS) f -= ITEMS;
   const int aq = f & 1, tq = (f >> 1) % QW, ahy = (f >> 1) / QW;
-  const int a_y = y0 - 1 + ahy, a_x = x0 - 1 + 4 * tq;
+  int a_x = 0;
   unsigned a_ok = 0;          // bit j: pixel a_x + j is inside the image (and the row is)
-  if (a_y >= 0 && a_y < p.H)
-    for (int j = 0; j < 6; ++j)
-      if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
-  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ ((tq >> 3) & 1)) << 2);   // float index of nu = 0
+  auto setup_item = [&]() {
+    const int a_y = y0 - 1 + ahy;
+    a_x = x0 - 1 + 4 * tq;
+    a_ok = 0;
+    if (a_y >= 0 && a_y < p.H)
+      for (int j = 0; j < 6; ++j)
+        if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
+  };
+  // K-half swap: QW >= 16 on bit 3 of the quad; QW = 8 (a 16-lane fragment read covers two halo rows of 8 quads) on the
+  // parity of the halo row - either way 16 consecutive fragment lanes cover all 64 banks once
+  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ (QW >= 16 ? ((tq >> 3) & 1) : (ahy & 1))) << 2);   // float index of nu = 0
   const int scol = aq * 4;
   unsigned a_off = 0, a_pix = 0;
   conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
@@ -137,7 +165,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     const int u = t + NT * i;
     const bool slot = u < BU;
     const int kb = u & 1, row = slot ? (u >> 1) % BN : 0, nu = slot ? (u >> 1) / BN : 0;
-    boff[i] = (unsigned)((size_t)(n0 + row) * nstage * 192 + nu * 32 + kb * 16);
+    boff[i] = (unsigned)((size_t)row * nstage * 192 + nu * 32 + kb * 16);   // + wbase (the channel block, uniform) in the scalar offset
     blds[i] = slot ? nu * B_PLANE + row * 8 + ((kb ^ ((row >> 3) & 1)) << 2) : -1;
   }
 
@@ -150,10 +178,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   unsigned bgoff[TN];
 #pragma unroll
   for (int nt = 0; nt < TN; ++nt)
-    bgoff[nt] = (unsigned)((size_t)(n0 + (ng * TN + nt) * 32 + l31) * nstage * 192 + (NU * h) * 32 + half * 16);
+    bgoff[nt] = (unsigned)((size_t)((ng * TN + nt) * 32 + l31) * nstage * 192 + (NU * h) * 32 + half * 16);
+  unsigned wbase = 0;   // byte offset of the channel block's weights: n0 * nstage * 192 (set per pair)
   auto load_bg = [&](int s, auto set_c) {
     constexpr int SET = decltype(set_c)::value;
-    const unsigned so = (unsigned)(s < nstage ? s : nstage - 1) * 192u;
+    const unsigned so = wbase + (unsigned)(s < nstage ? s : nstage - 1) * 192u;
 #pragma unroll
     for (int j = 0; j < (BG ? NU : 1); ++j)
 #pragma unroll
@@ -194,7 +223,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
   };
   auto load_b = [&](int s, int buf) {
-    const unsigned so = (unsigned)(s < nstage ? s : nstage - 1) * 192u;
+    const unsigned so = wbase + (unsigned)(s < nstage ? s : nstage - 1) * 192u;
 #pragma unroll
     for (int i = 0; i < BLD; ++i) breg[buf][i] = conv_buf_load(brsrc, boff[i], so);
   };
@@ -205,6 +234,38 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       if (NT * (i + 1) <= BU || blds[i] >= 0) *reinterpret_cast<bf4*>(Bs + blds[i]) = breg[buf][i];
   };
 
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  const int sb = kbeg * 3;
+  // per pair (decode() done): staging state and EVERY load request of the prologue - chunk 0 (PF2: and chunk 1) of the
+  // activations, the first weight stages; the LDS stores follow at the top of the pair loop (one load latency, not three)
+  auto begin_pair_a = [&]() {
+    setup_item();
+    sg = 0; c0 = 0; chunk_ok = true;
+    for (int skip = kbeg * 8; skip > 0;) {   // first chunk of this split: walk the concat segments
+      const int cseg = p.seg[sg].C;
+      if (skip >= cseg) { skip -= cseg; ++sg; } else { c0 = skip; skip = 0; }
+    }
+    setup_seg();
+    load_item(C0{});
+  };
+  auto begin_pair_b = [&]() {
+    wbase = (unsigned)n0 * (unsigned)nstage * 192u;
+    if constexpr (BG) {
+      load_bg(sb + 0, C0{});
+      load_bg(sb + 1, C1{});
+    } else {
+      load_b(sb + 0, 0);
+      load_b(sb + 1, 1);
+      load_b(sb + 2, 2);
+    }
+    if constexpr (PF2) { next_chunk(kbeg + 1); load_item(C1{}); }   // chunk 1 stays in registers until chunk 0's dy = 1 stage
+  };
+  begin_pair_a();
+  begin_pair_b();
+
+  while (true) {
+  const int cimg = img, cy0 = y0, cx0 = x0, cn0 = n0;   // the pair the accumulators below belong to (img .. n0 move on early)
   f32x16 acc[TM][NU][TN];   // [row][nu - NU*h][channel tile]
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -220,7 +281,8 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   constexpr int A_STAGE4 = A_STAGE / 4, B_STAGE4 = B_STAGE / 4, B_PLANE4 = B_PLANE / 4;
   const int wm = rg * TM;                    // first MFMA row tile of this wave
   const int lrow = l31 / QW, lq = l31 % QW;  // lane -> (patch row inside the tile, quad)
-  const int swb = (lq >> 3) & 1;
+  const int swb = (l31 >> 3) & 1;            // = bit 3 of the quad (QW >= 16) / parity of the tile row (QW = 8), and bit 3 of the channel
+  // QW = 8: the halo row read at (mt, dy) is wm * 4 + lrow + mt * 4 + dy, parity (lrow + dy) & 1: odd dy flips the low bit
   const int a_ad = (((wm * RPT + lrow) * 6 + NU * h) * QW + lq) * 2 + (half ^ swb);     // + ((mt * RPT + dy) * 6 + j) * QW * 2, stage
   const int b_ad = 2 * A_STAGE4 + (NU * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
   int a_cur = a_ad;
@@ -230,8 +292,9 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   auto fetch = [&](auto dy_c, auto j_c, int a_base) {
     constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
     if constexpr ((FLAGS & W43_DBG_NOFRAG) != 0) { if (in_loop) return; }
+    const int ab = (QW == 8 && (DY & 1)) ? (a_base ^ 1) : a_base;
 #pragma unroll
-    for (int mt = 0; mt < TM; ++mt) fa[J % 3][mt] = smem4[a_base + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
+    for (int mt = 0; mt < TM; ++mt) fa[J % 3][mt] = smem4[ab + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
     if constexpr (!BG) {
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) fb[J % 3][nt] = smem4[b_ad + DY * B_STAGE4 + J * B_PLANE4 + nt * 64];
@@ -251,24 +314,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
-  using C0 = std::integral_constant<int, 0>;
-  using C1 = std::integral_constant<int, 1>;
-  for (int skip = kbeg * 8; skip > 0;) {   // first chunk of this split: walk the concat segments
-    const int cseg = p.seg[sg].C;
-    if (skip >= cseg) { skip -= cseg; ++sg; } else { c0 = skip; skip = 0; }
-  }
-  setup_seg();
-  const int sb = kbeg * 3;
-  load_item(C0{});    // every request of the prologue first, then the stores: one load latency instead of three
-  if constexpr (BG) {
-    load_bg(sb + 0, C0{});
-    load_bg(sb + 1, C1{});
-  } else {
-    load_b(sb + 0, 0);
-    load_b(sb + 1, 1);
-    load_b(sb + 2, 2);
-  }
-  if constexpr (PF2) { next_chunk(kbeg + 1); load_item(C1{}); }   // chunk 1 stays in registers until chunk 0's dy = 1 stage
+  a_cur = a_ad;
   store_item(0, C0{});
   if constexpr (!BG) {
     store_b(0, 0);
@@ -333,6 +379,18 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
 
   if constexpr (BG && NH == 2) __syncthreads();   // no barrier behind the last dy = 2 stage: the exchange below reuses the activation buffers
 
+  // ---- the next pair of this workgroup (persistent launches): its first loads are in flight during the epilogue ------------
+  constexpr bool PERS = (FLAGS & W43_F_PERSIST) != 0;
+  constexpr int PRE = (FLAGS & W43_F_PRE2) ? 2 : (FLAGS & W43_F_PRE1) ? 1 : 0;
+  static_assert(PERS || PRE == 0, "PRE flags need W43_F_PERSIST");
+  lin += stride;
+  const bool more = PERS && lin < total;
+  if (more) {
+    decode(lin);
+    if constexpr (PRE >= 1) begin_pair_a();
+    if constexpr (PRE >= 2) begin_pair_b();
+  }
+
   // ---- epilogue: y0 = (m0+m1+m2) + (m3+m4), y1 = (m1-m2) + 2(m3-m4) on half 0; y2 = (m1+m2) + 4(m3+m4),
   // y3 = (m1-m2) + (8(m3-m4) + m5) on half 1.  The halves swap the bracketed sums they lack through LDS (the staging
   // buffers are free after the last barrier), one tile per round.  C/D layout of the 32x32 MFMA: col = lane&31 (cout),
@@ -363,7 +421,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       __syncthreads();
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) {
-        const int n = n0 + (ng * TN + nt) * 32 + l31;
+        const int n = cn0 + (ng * TN + nt) * 32 + l31;
         const float bv = p.bias[n];
 #pragma unroll
         for (int mt = 0; mt < TM; ++mt) {
@@ -371,38 +429,40 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row MFMA tile
-            const int y = y0 + (wm + mt) * RPT + mrow / QW;
-            const int x = x0 + 4 * (mrow % QW) + 2 * H + round;
+            const int y = cy0 + (wm + mt) * RPT + mrow / QW;
+            const int x = cx0 + 4 * (mrow % QW) + 2 * H + round;
             const float got = take[((mt * TN + nt) * 16 + r) * 64];
             const float ma = acc[mt][1][nt][r], mb = acc[mt][2][nt][r], m0 = acc[mt][0][nt][r];
             float v;
             if (H == 0) v = round == 0 ? ((m0 + ma) + mb) + got : (ma - mb) + got;                       // y0, y1
             else v = round == 0 ? got + 4.f * (m0 + ma) : got + (8.f * (m0 - ma) + mb);                  // y2, y3
             if (ksp > 1) {   // split-K: raw partial sum; bias, activation and the sum over the splits in the reduce kernel
-              if (y < p.H && x < p.W) p.part[((size_t)blockIdx.z * p.M + ((size_t)img * p.H + y) * p.W + x) * p.Cout + n] = v;
+              if (y < p.H && x < p.W) p.part[((size_t)blockIdx.z * p.M + ((size_t)cimg * p.H + y) * p.W + x) * p.Cout + n] = v;
               continue;
             }
             v += bv;
             if (p.leaky) v = v > 0.f ? v : 0.2f * v;
             val[r] = v;
-            if (y < p.H && x < p.W) p.out[(((size_t)img * p.H + y) * p.W + x) * p.ostride + n] = v;
+            if (y < p.H && x < p.W) p.out[(((size_t)cimg * p.H + y) * p.W + x) * p.ostride + n] = v;
           }
-          if constexpr (QW == 16) {
-            // fused 2x2 average pool: this lane holds rows 2k (r < 8) and 2k + 1 (r >= 8) of quad q = mrow % 16 at
-            // x = 4q + 2H (round 0, kept) and x + 1 (round 1)
+          if constexpr (QW <= 16) {
+            // fused 2x2 average pool: this lane holds patch rows 2k (register r) and 2k + 1 (register r + QW / 2) of quad
+            // q = mrow % QW at x = 4q + 2H (round 0, kept) and x + 1 (round 1)
             if (p.pool_out != nullptr && ksp == 1) {
               if (round == 0) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) keep[mt][nt][r] = val[r];
               } else {
-                const int yp = (y0 >> 1) + wm + mt;
 #pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                  const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
-                  const int xp = (x0 >> 1) + 2 * q + H;
-                  const float pv = (((keep[mt][nt][r] + val[r]) + keep[mt][nt][r + 8]) + val[r + 8]) * 0.25f;
+                for (int r = 0; r < 16; ++r) {
+                  if ((r / (QW / 2)) & 1) continue;      // the odd row of a pair
+                  const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+                  const int q = mrow % QW;
+                  const int yp = (cy0 >> 1) + (((wm + mt) * RPT + mrow / QW) >> 1);
+                  const int xp = (cx0 >> 1) + 2 * q + H;
+                  const float pv = (((keep[mt][nt][r] + val[r]) + keep[mt][nt][r + QW / 2]) + val[r + QW / 2]) * 0.25f;
                   if (2 * yp < p.H && 2 * xp < p.W)
-                    p.pool_out[(((size_t)img * (p.H >> 1) + yp) * (p.W >> 1) + xp) * p.pool_ostride + n] = pv;
+                    p.pool_out[(((size_t)cimg * (p.H >> 1) + yp) * (p.W >> 1) + xp) * p.pool_ostride + n] = pv;
                 }
               }
             }
@@ -416,7 +476,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     else finish(std::integral_constant<int, 1>{});
   } else {
     // all six planes in this wave: the same sums, in the same order, as the two-half exchange above
-    const int n = n0 + ng * 32 + l31;
+    const int n = cn0 + ng * 32 + l31;
     const float bv = p.bias[n];
     auto outputs = [&](int r, float* o) {
       const float m0 = acc[0][0][0][r], m1 = acc[0][1][0][r], m2 = acc[0][2][0][r], m3 = acc[0][3][0][r], m4 = acc[0][4][0][r],
@@ -426,11 +486,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       o[2] = (m1 + m2) + 4.f * (m3 + m4);
       o[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
       const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
-      const int y = y0 + wm * RPT + mrow / QW;
-      const int x = x0 + 4 * (mrow % QW);
+      const int y = cy0 + wm * RPT + mrow / QW;
+      const int x = cx0 + 4 * (mrow % QW);
       if (ksp > 1) {   // split-K: raw partial sums
         if (y < p.H) {
-          const size_t pix = ((size_t)img * p.H + y) * p.W + x;
+          const size_t pix = ((size_t)cimg * p.H + y) * p.W + x;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (x + j < p.W) p.part[((size_t)blockIdx.z * p.M + pix + j) * p.Cout + n] = o[j];
@@ -443,16 +503,16 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
         if (p.leaky) o[j] = o[j] > 0.f ? o[j] : 0.2f * o[j];
       }
       if (y < p.H) {
-        const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+        const size_t rowbase = ((size_t)cimg * p.H + y) * p.W;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (x + j < p.W) p.out[(rowbase + x + j) * p.ostride + n] = o[j];
       }
     };
-    if (QW == 16 && BN == 64 && p.pw_out != nullptr) {
-      // fused 1x1 convolution: the activated tile goes to LDS as [pixel = patch row * 64 + x][65] (the K loop ended with a
+    if (QW <= 16 && BN == 64 && p.pw_out != nullptr) {
+      // fused 1x1 convolution: the activated tile goes to LDS as [pixel = patch row * PXW + x][65] (the K loop ended with a
       // barrier: the staging buffers are free), then thread = pixel sums its 64 channels
-      static_assert(NH != 1 || QW != 16 || BN != 64 || (size_t)TH * 64 * 65 <= 2 * A_STAGE + 3 * B_STAGE, "1x1 tile does not fit");
+      static_assert(NH != 1 || QW > 16 || BN != 64 || (size_t)TH * PXW * 65 <= 2 * A_STAGE + 3 * B_STAGE, "1x1 tile does not fit");
       float* const tile = smem;
       if constexpr (BG) __syncthreads();   // (no barrier behind the last stage of the K loop)
 #pragma unroll
@@ -465,7 +525,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
         o[2] = (m1 + m2) + 4.f * (m3 + m4);
         o[3] = (m1 - m2) + (8.f * (m3 - m4) + m5);
         const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int pxl = (wm * RPT + mrow / QW) * 64 + 4 * (mrow % QW);
+        const int pxl = (wm * RPT + mrow / QW) * PXW + 4 * (mrow % QW);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           float v = o[j] + bv;
@@ -474,8 +534,8 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
         }
       }
       __syncthreads();
-      if (t < TH * 64) {
-        const int y = y0 + t / 64, x = x0 + (t & 63);
+      if (t < TH * PXW) {
+        const int y = cy0 + t / PXW, x = cx0 + (t % PXW);
         float a[4] = {0.f, 0.f, 0.f, 0.f};
         const float* row = tile + t * 65;
 #pragma unroll 8
@@ -486,25 +546,27 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
             if (j < p.pw_cout) a[j] = __builtin_fmaf(v, p.pw_w[c * p.pw_cout + j], a[j]);
         }
         if (y < p.H && x < p.W) {
-          float* d = p.pw_out + (((size_t)img * p.H + y) * p.W + x) * p.pw_ostride;
+          float* d = p.pw_out + (((size_t)cimg * p.H + y) * p.W + x) * p.pw_ostride;
 #pragma unroll
           for (int j = 0; j < 4; ++j)
             if (j < p.pw_cout) d[j] = a[j] + p.pw_bias[j];
         }
       }
-    } else if (QW == 16 && p.pool_out != nullptr && ksp == 1) {
-      const int yp = (y0 >> 1) + wm;
+    } else if (QW <= 16 && p.pool_out != nullptr && ksp == 1) {
 #pragma unroll
-      for (int r = 0; r < 8; ++r) {      // rows 2k (r) and 2k + 1 (r + 8) of the same quad
+      for (int r = 0; r < 16; ++r) {      // patch rows 2k (r) and 2k + 1 (r + QW / 2) of the same quad
+        if ((r / (QW / 2)) & 1) continue;
         float t[4], bq[4];
         outputs(r, t);
-        outputs(r + 8, bq);
-        const int q = (r & 3) + 8 * (r >> 2) + 4 * half;
+        outputs(r + QW / 2, bq);
+        const int mrow = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int q = mrow % QW;
+        const int yp = (cy0 >> 1) + ((wm * RPT + mrow / QW) >> 1);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int xp = (x0 >> 1) + 2 * q + e;
+          const int xp = (cx0 >> 1) + 2 * q + e;
           const float pv = (((t[2 * e] + t[2 * e + 1]) + bq[2 * e]) + bq[2 * e + 1]) * 0.25f;
-          if (2 * yp < p.H && 2 * xp < p.W) p.pool_out[(((size_t)img * (p.H >> 1) + yp) * (p.W >> 1) + xp) * p.pool_ostride + n] = pv;
+          if (2 * yp < p.H && 2 * xp < p.W) p.pool_out[(((size_t)cimg * (p.H >> 1) + yp) * (p.W >> 1) + xp) * p.pool_ostride + n] = pv;
         }
       }
     } else {
@@ -515,6 +577,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       }
     }
   }
+  if (!more) break;
+  if constexpr (PRE < 1) begin_pair_a();
+  if constexpr (PRE < 2) begin_pair_b();
+  __syncthreads();   // every wave is through with the exchange buffer / the 1x1 tile / its last fragment reads: the staging buffers are free
+  }   // pair loop
 }
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
@@ -535,6 +602,18 @@ hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
   }
   const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
+  if (p.persist > 0 && (FLAGS & W43_F_PERSIST) != 0) {   // persistent: `persist` workgroups per CU walk the pairs with stride = the grid size
+    static int ncu[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (!ncu[dev]) {
+      hipDeviceProp_t prop;
+      ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const long long pairs = (long long)grid.x * grid.y, g = (long long)p.persist * ncu[dev];
+    if (g < pairs) grid = dim3((unsigned)g, 1, grid.z);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();
 }

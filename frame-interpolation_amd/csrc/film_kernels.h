@@ -69,6 +69,10 @@ struct ConvParams {
   const float* pw_bias;
   float* pw_out;
   int pw_ostride, pw_cout;   // pw_cout <= 4
+  // conv_wino43_kernel: > 0 = PERSISTENT launch with this many workgroups per CU (per K split); every workgroup walks the
+  // (patch, channel block) pairs lin, lin + G, ... and requests the first loads of its next pair in front of the epilogue of
+  // the current one.  0: one workgroup per pair.  Same sums either way (bit-identical results).
+  int persist;
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,
@@ -197,6 +201,7 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                                       weights [Cout][chunk][dy][j][h][plane][16] bf16 */,
                 CONV_TILE_F43 = 2048 /* with CONV_TILE_WINO: conv_wino43_kernel (F(4,3) along x, fp32): shape index = Wino43Tile,
                                         weights [Cout][chunk of 8][dy][nu 6][8] */,
+                CONV_TILE_EXT = 4096 /* conv_wino43_kernel: shape index = (tile & 15) + 16 */,
                 CONV_TILE_FOLDX3 = 1024 /* conv_foldx3_kernel (precision mode bf16x3, folded upsample + 2x2): shape index =
                                            FoldX3Tile, weights [Cout][chunk][9 (tap, phase) steps][plane][16] bf16 */ };
 // conv_wino43_kernel tiles (CONV_TILE_WINO | CONV_TILE_F43): patch rows x 128 pixels x output channels, wave block TM x TN
@@ -208,7 +213,14 @@ enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_
                   W43_Q16_4x64_T21_P2 = 7, W43_Q16_4x64_T12_P2 = 8, W43_Q16_4x32_T11_P2 = 9, W43_Q16_4x64_N1_P2 = 10,
                   /* the 32-channel Q16 tile with the weight fragments read straight from global memory (no weight ring: 36 KB of
                      LDS, <= 128 VGPRs -> FOUR workgroups per CU; the short K loops of the 32-channel layers are latency bound) */
-                  W43_Q16_4x32_T11_BG = 11 };
+                  W43_Q16_4x32_T11_BG = 11,
+                  /* "Q8": 32-pixel patches, 8 rows (an MFMA row tile = FOUR patch rows x 8 quads): the same 256 pixels per
+                     workgroup, no empty quads on the 15 * 2^k wide levels, 10 halo rows per 8 output rows; all with the
+                     activation loads two chunks ahead */
+                  W43_Q8_8x64_T21_P2 = 12, W43_Q8_8x64_N1_P2 = 13, W43_Q8_8x32_T11_BG = 14, W43_Q8_8x64_T12_P2 = 15,
+                  /* ids >= 16 carry CONV_TILE_EXT in the tile id (shape = (tile & 15) + 16).  The 32-channel Q8 tile WITH the
+                     weight ring: 48 KB of LDS, 152 VGPRs -> three workgroups per CU (flow level 0 conv_0: -7 % against the BG tile) */
+                  W43_Q8_8x32_T11_P2 = 16 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

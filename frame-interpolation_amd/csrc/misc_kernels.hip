@@ -255,18 +255,25 @@ __device__ __forceinline__ float2 warp_flow_at(const WarpParams& p, int64_t b, i
 // the source rows that neighbouring output rows share (fy+1 of row y = fy of row y+1 for smooth flows) are fetched
 // by the same CU within a few hundred cycles instead of by workgroups spread over the eight XCDs' L2s
 // (one row per workgroup: 2.3x over-fetch at the fabric, L2 hit rate 25 %, profiles/r01_pmc_summary.md).
+// Feature units: a workgroup = 16 consecutive pixels x ONE 64-channel slice (16 float4 groups) x the 8 rows of the band, so
+// that the corner pixels neighbouring outputs share (tr of x = tl of x + 1 for smooth flows) are read by the same workgroup
+// whatever the channel count - with the round-2 mapping (256 consecutive (pixel, group) units of a row) a workgroup covered
+// one pixel of a 960-channel level and every source pixel was fetched by up to four workgroups on different CUs / XCDs
+// (read over-fetch 1.57x at the fabric, profiles/r02_pmc_summary.md).  blockIdx.x = x tile * slices + slice; the image /
+// flow-packing units follow behind the feature workgroups as before.
 constexpr int WARP_ROWS = 8;
+constexpr int WARP_TX = 16;    // pixels of a feature workgroup
 __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int G = p.C >> 2;
-  const unsigned i = blockIdx.x * 256u + threadIdx.x;
-  const unsigned nfeat = (unsigned)(p.W * G);
+  const unsigned nsl = (unsigned)(G + 15) >> 4;
+  const unsigned nfeat_blocks = ((unsigned)(p.W + WARP_TX - 1) / WARP_TX) * nsl;
   const int yb = blockIdx.y * WARP_ROWS;
   const int64_t b = blockIdx.z;
-  if (i >= nfeat) {
+  if (blockIdx.x >= nfeat_blocks) {
     // image units of the band (behind its feature units; only the last workgroups have any): one thread = one pixel
     // of one row of the band, 3 channels
     const unsigned band = (unsigned)(p.W * WARP_ROWS);
-    unsigned u = i - nfeat;
+    unsigned u = (blockIdx.x - nfeat_blocks) * 256u + threadIdx.x;
     if (p.src3 == nullptr || u >= band) {
       // flow-packing units (behind the image units): one thread = one pixel
       if (p.src3 != nullptr) u -= band;
@@ -302,8 +309,9 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
     for (int c = 0; c < 3; ++c) d[c] = lerp3(s00[c], s00[p.s3stride + c], s10[c], s10[p.s3stride + c], ax, ay);
     return;
   }
-  int x, g;
-  split_unit(i, G, x, g);
+  const unsigned xt = blockIdx.x / nsl, sl = blockIdx.x - xt * nsl;
+  const int x = (int)(xt * WARP_TX + (threadIdx.x >> 4)), g = (int)(sl * 16 + (threadIdx.x & 15));
+  if (x >= p.W || g >= G) return;
   const int64_t rowpitch = (int64_t)p.W * p.sstride;
   const float* const img = p.src + b * p.H * rowpitch + g * 4;
 #pragma unroll
@@ -442,8 +450,9 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
     if (p.flow_out != nullptr || p.src3 != nullptr || p.pack_dst != nullptr) return hipErrorInvalidValue;
     hipLaunchKernelGGL(warp_c3_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB), dim3(256), 0, s, p);
   } else {
-    const int64_t all = units + ((p.src3 != nullptr) + (p.pack_dst != nullptr)) * (int64_t)p.W * WARP_ROWS;
-    hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)((all + 255) / 256), (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB),
+    const int64_t feat_blocks = (int64_t)((p.W + WARP_TX - 1) / WARP_TX) * ((p.C / 4 + 15) / 16);
+    const int64_t extra = ((p.src3 != nullptr) + (p.pack_dst != nullptr)) * (int64_t)p.W * WARP_ROWS;
+    hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)(feat_blocks + (extra + 255) / 256), (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB),
                        dim3(256), 0, s, p);
   }
   return hipGetLastError();

@@ -25,7 +25,10 @@ published definitions.
         .../convs/{i}/{j}/{kernel,bias}, .../output_conv/...  fusion.py:64-101
     (UNVERIFIED against a real published checkpoint: none is reachable from this environment.  The mapping is
     therefore pattern based, independent of the `layer_with_weights-N` numbering, and falls back to matching by
-    tensor shape in key order; `load_film_weights` reports which rule placed every tensor.)
+    tensor shape only where the shape is unique; `load_film_weights` reports which rule placed every tensor and logs a
+    warning whenever one was placed by shape.  tests/tf_like_writer.py is a second, independently written writer that
+    lays a bundle out the way TensorFlow's writers do - several shards, multi-block index with shortest separators,
+    Adam slot variables, int64 counters, a real TrackableObjectGraph - and the reader is tested against it.)
 
 crc32c (Castagnoli) of large shards is computed by the native helper in libfilm_hip.so (film_crc32c) when the
 library is built; a table-driven pure-Python fallback covers the (small) index blocks.
@@ -447,6 +450,12 @@ def load_film_weights(prefix: str, opt=None, verify: bool = True, report: Option
     if still:
         raise KeyError(f'{prefix}: no variable found for {still[:4]}{"..." if len(still) > 4 else ""} '
                        f'({len(still)} of {len(specs)} tensors); keys look like {var_keys[:3]}')
+    by_shape = sorted(n for n, (rule, _) in rep.items() if rule != 'path')
+    if by_shape:   # say so by default: a tensor placed by its shape is a (unique-shape) guess, not a name match
+        import logging
+        logging.getLogger('film_hip.tf_bundle').warning(
+            '%s: %d of %d tensors were not found under a known object-graph path and were placed by their (unique) shape: %s',
+            prefix, len(by_shape), len(specs), ', '.join(f'{n} <- {rep[n][1]}' for n in by_shape))
     return out
 
 

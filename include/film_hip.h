@@ -142,9 +142,13 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  case, 4.4e-6 rms, zero mean (not an fp32 result; 7e-6 from the oracle end to end against the 1e-3
  *                  image bound, see tests).
  *                  Changing it drops the cached plans.
- *   "lanes"   0/1  replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
- *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain
- *                  (default 1); ordering between the two comes from a buffer-overlap analysis of the plan
+ *   "lanes"   0/1/2  >= 1 (default 1): replay graphs run the independent small / HBM-bound kernels (feature subtrees of the coarse
+ *                  pyramid levels, coarse flow levels, the t = 0.5 warps) on a second stream beside the main chain;
+ *                  2 (measured 2 % slower at 1080p, not the default): on frames larger than 512 x 512 the coarse decoder levels (>= 2) join that stream right behind
+ *                  the aligned levels they read, so that their matrix-bound convolutions run beside the flow estimator's
+ *                  chain of HBM-bound warps and short launches instead of behind it.  Ordering between the two streams
+ *                  comes from a buffer-overlap analysis of the plan.  3 = the same on frames of any size (tests).  Drops the
+ *                  cached plans.
  *   "splitk"  0/1  1 (default): the deep convolutions of pyramid levels with <= 4096 pixels per image run split-K
  *                  (2-16 partial sums over K ranges, added in split order by a second kernel: deterministic, and the
  *                  factor depends on the level size and the layer only, never on the batch); it is what bounds the
@@ -170,6 +174,8 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.
+ *   "w43_shape" n  test knob: every convolution on conv_wino43_kernel that can run tile shape n (Wino43Tile, film_kernels.h)
+ *                  does, instead of the autotuned shape; -1 (default) = autotuned.  Results cannot change.  Drops the cached plans.
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in limits: 64 GiB of
  *                  workspace, 4 GiB per buffer read through a whole-buffer 32-bit offset); frame pairs are independent,
  *                  results do not change */

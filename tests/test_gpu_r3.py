@@ -281,3 +281,37 @@ def test_parity_with_flows_that_leave_the_frame_at_every_level():
     assert fmax > 32.0 and min(outside) > 0.0
     assert e_hip64 < IMAGE_TOL and e_hip32 < IMAGE_TOL
     assert e_hip64 <= max(8 * e_or, 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# conv_wino43_kernel: every tile shape (incl. the round-3 32-pixel x 8-row "Q8" tiles) gives the same bits
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('b,h,w', [(1, 128, 320), (2, 192, 256), (1, 64, 960)])
+def test_every_f43_tile_shape_gives_the_same_bits(published, b, h, w):
+    """F(4,3) forced onto every eligible 3x3 layer ("winograd" = 3), then every Wino43Tile shape forced in turn ("w43_shape"):
+    image, the feature pyramid (fused pools) and the aligned pyramid are bit-identical to the autotuned plan - the sums are
+    the same k-ordered chains whatever the tile.  Covers the Q8 tiles on widths that fill / do not fill 32- and 64-pixel
+    patches, the fused average pool of the sub-extractor stages and the fused RGB head."""
+    from film_hip.engine import FilmEngine
+    opt, wts, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(wts)
+    eng.set_option('winograd', 3)
+    x0, x1 = TI.frame_pair(b, h, w, seed=31)
+    ref = eng.forward(x0, x1)
+    taps = {k: eng.tap(k) for k in ('feat0', 'feat2', 'aligned0', 'aligned1')}
+    used = set()
+    for shape in range(17):
+        eng.set_option('w43_shape', shape)
+        tiles = {((o['tile'] & 15) + (16 if o['tile'] & 4096 else 0)) for o in eng.plan(b, h, w)['ops']
+                 if o['kind'] == 'conv_mfma' and (o['tile'] & 2048)}
+        if shape not in tiles:
+            continue          # no layer of this plan can run the shape
+        used.add(shape)
+        got = eng.forward(x0, x1)
+        assert np.array_equal(got, ref), (shape, float(np.abs(got - ref).max()))
+        for k, v in taps.items():
+            assert np.array_equal(eng.tap(k), v), (shape, k)
+    print('F(4,3) tile shapes exercised:', sorted(used))
+    assert {12, 13, 14, 16} <= used        # the Q8 tiles ran
+    eng.close()

@@ -181,6 +181,17 @@ def test_plan_interpreter_matches_oracle_published_64(published_packed):
     assert abs(flops / (64 * 64) - 4246240.6875) / 4246240.6875 < 1e-5
     warp_bytes = sum(op['bytes'] for op in plan['ops'] if op['kind'] == 'warp')
     assert abs(warp_bytes / (64 * 64) - 5201.58) / 5201.58 < 1e-3
+    # "lanes" = 3: the op order of large frames (coarse decoder levels emitted right behind the aligned levels they read,
+    # on the side lane) at this small size - same ops, same bits through the interpreter
+    eng.set_option('lanes', 3)
+    plan3 = eng.plan(1, 64, 64)
+    eng.set_option('lanes', 1)
+    tags, tags3 = [o['tag'] for o in plan['ops']], [o['tag'] for o in plan3['ops']]
+    assert sorted(tags) == sorted(tags3) and tags != tags3
+    assert {o['lane'] for o in plan3['ops'] if o['tag'].startswith(('fusion_l3', 'fusion_l2'))} == {1}
+    assert {o['lane'] for o in plan3['ops'] if o['tag'].startswith(('fusion_l1', 'fusion_l0'))} == {0}
+    arena3 = pi.run_plan(plan3, layouts, x0, x1)
+    assert np.array_equal(pi.tap(plan3, arena3, 'out'), pi.tap(plan, arena, 'out'))
 
 
 def test_precision_modes_choose_kernel_families_by_shape_only():
@@ -268,8 +279,10 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
     program order (happens-before closure computed here independently from the plan JSON)."""
     from film_hip.engine import FilmEngine
     from film_hip.options import PUBLISHED, TINY
-    for opt, shape in ((TINY, (2, 64, 96)), (PUBLISHED, (1, 128, 192))):
+    for opt, shape, lanes in ((TINY, (2, 64, 96), 1), (PUBLISHED, (1, 128, 192), 1), (PUBLISHED, (4, 576, 960), 1),
+                              (PUBLISHED, (4, 576, 960), 2)):   # the last: option "lanes" = 2, coarse decoder levels on the side lane
         eng = FilmEngine(opt, device=-1)
+        eng.set_option('lanes', lanes)
         plan = eng.plan(*shape)
         bufs = {b['name']: b for b in plan['buffers']}
         ops = plan['ops']

@@ -128,3 +128,73 @@ def test_shape_fallback_places_only_unambiguous_tensors(tmp_path, tiny_weights):
     tb.write_bundle(prefix, tensors, object_graph=False)
     with pytest.raises(KeyError):
         tb.load_film_weights(prefix, TINY)
+
+
+def _paths(weights, opt):
+    from film_hip import tf_bundle as tb
+    return {tb.checkpoint_key(n, opt)[:-len(tb.VAR_SUFFIX)]: w for n, w in weights.items()}
+
+
+def test_reader_against_a_tensorflow_like_bundle(tmp_path, tiny_weights, caplog):
+    """the reader on a bundle written by a SECOND writer (tests/tf_like_writer.py, no code shared with
+    film_hip/tf_bundle.py) that follows TensorFlow's own layout: two data shards with padding between tensors, a
+    multi-block index with restart interval 16, prefix compression and shortest-separator index keys, Adam slot variables
+    of the same shapes under .OPTIMIZER_SLOT, int64 `optimizer/iter` / `save_counter`, float hyper-parameters, and the
+    `_CHECKPOINTABLE_OBJECT_GRAPH` as a real TrackableObjectGraph (children edges, attributes, slot_variables)."""
+    import logging
+    import tf_like_writer as tw
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    full = {tb.checkpoint_key(n, TINY)[:-len(tb.VAR_SUFFIX)]: n for n in tiny_weights}    # Keras variable names
+    model_dir = tmp_path / 'saved_model'
+    prefix = str(model_dir / 'variables' / 'variables')
+    facts = tw.write_tf_like_bundle(prefix, _paths(tiny_weights, TINY), full_names=full, num_shards=2, block_size=384)
+    assert facts['data_blocks'] > 8 and facts['shards'] == 2
+    assert os.path.isfile(prefix + '.data-00001-of-00002')
+    rd = tb.BundleReader(prefix)
+    assert rd.num_shards == 2 and len(rd.entries) == facts['entries']
+    assert {e.shard_id for e in rd.entries.values()} == {0, 1}
+    og = rd.object_graph_keys()                                   # parsed from the node / attribute structure
+    assert len(og) == 3 * len(tiny_weights) + 6                   # variables + their m / v slots + 5 optimizer scalars + save_counter
+    for n in tiny_weights:
+        assert og[tb.checkpoint_key(n, TINY)] == n
+    report = {}
+    with caplog.at_level(logging.WARNING, logger='film_hip.tf_bundle'):
+        got = tb.load_film_weights(prefix, TINY, report=report)
+    assert not caplog.records                                     # everything placed by its path: nothing to warn about
+    assert set(got) == set(tiny_weights) and all(rule == 'path' for rule, _ in report.values())
+    for k in tiny_weights:
+        assert np.array_equal(got[k], tiny_weights[k]), k         # never an Adam slot of the same shape
+    via = W.load_weights(str(model_dir), TINY)                    # the loader behind Interpolator(model_path)
+    assert all(np.array_equal(via[k], tiny_weights[k]) for k in tiny_weights)
+    # one shard, one block (what a small real checkpoint looks like) reads the same
+    facts1 = tw.write_tf_like_bundle(str(tmp_path / 'one' / 'variables'), _paths(tiny_weights, TINY), num_shards=1, block_size=1 << 20)
+    assert facts1['data_blocks'] == 1
+    got1 = tb.load_film_weights(str(tmp_path / 'one' / 'variables'), TINY)
+    assert all(np.array_equal(got1[k], tiny_weights[k]) for k in tiny_weights)
+    # corruption in the SECOND shard is caught by the per-tensor crc32c
+    fn = prefix + '.data-00001-of-00002'
+    raw = bytearray(open(fn, 'rb').read())
+    raw[len(raw) // 2] ^= 0x10
+    open(fn, 'wb').write(raw)
+    with pytest.raises(ValueError, match='crc32c'):
+        tb.load_film_weights(prefix, TINY)
+
+
+def test_shape_placed_tensors_are_logged(tmp_path, tiny_weights, caplog):
+    """load_film_weights says so (logging.warning) whenever a tensor was placed by its shape instead of its path."""
+    import logging
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    names = [n for spec, _, _ in W.weight_specs(TINY) for n in (spec + '/kernel', spec + '/bias')]
+    shapes = [tuple(tiny_weights[n].shape) for n in names]
+    odd = next(n for n in names if shapes.count(tuple(tiny_weights[n].shape)) == 1)
+    tensors = {(f'model/variables/0{tb.VAR_SUFFIX}' if n == odd else tb.checkpoint_key(n, TINY)): tiny_weights[n] for n in names}
+    prefix = str(tmp_path / 'variables' / 'variables')
+    tb.write_bundle(prefix, tensors, object_graph=False)
+    with caplog.at_level(logging.WARNING, logger='film_hip.tf_bundle'):
+        got = tb.load_film_weights(prefix, TINY)
+    assert np.array_equal(got[odd], tiny_weights[odd])
+    assert len(caplog.records) == 1 and odd in caplog.records[0].getMessage() and 'placed by their (unique) shape' in caplog.records[0].getMessage()

@@ -62,6 +62,14 @@ struct Variant { const char* name; int bm, bn, bkc; int wkind; LaunchFn fn; };  
 #define F43(TH, BN, TM, TN) {"wino43 " #TH "x128x" #BN " t" #TM "x" #TN " f4", TH * 128, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, 4>}
 #define F43Q(TH, BN, TM, TN, FL) {"wino43 q16 " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, FL, 16>}
 #define F43N(TH, BN, FL) {"wino43 q16 nh1 " #TH "x64x" #BN " t1x1 f" #FL, TH * 64, BN, 8, 7, conv_wino43_launch<TH, BN, 1, 1, FL, 16, 1>}
+#define F43Q8(TH, BN, TM, TN, FL) {"wino43 q8 " #TH "x32x" #BN " t" #TM "x" #TN " f" #FL, TH * 32, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, FL, 8>}
+#define F43N8(TH, BN, FL) {"wino43 q8 nh1 " #TH "x32x" #BN " t1x1 f" #FL, TH * 32, BN, 8, 7, conv_wino43_launch<TH, BN, 1, 1, FL, 8, 1>}
+template <LaunchFn F, int G>
+hipError_t persist_launch(const ConvParams& p, hipStream_t s) { ConvParams q = p; q.persist = G; return F(q, s); }
+#define PQ8(TH, BN, TM, TN, FL, G) {"wino43 q8 pers" #G " " #TH "x32x" #BN " t" #TM "x" #TN " f" #FL, TH * 32, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, TM, TN, FL, 8>, G>}
+#define PN8(TH, BN, FL, G) {"wino43 q8 nh1 pers" #G " " #TH "x32x" #BN " t1x1 f" #FL, TH * 32, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, 1, 1, FL, 8, 1>, G>}
+#define PQ(TH, BN, TM, TN, FL, G) {"wino43 q16 pers" #G " " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, TM, TN, FL, 16>, G>}
+#define PN(TH, BN, FL, G) {"wino43 q16 nh1 pers" #G " " #TH "x64x" #BN " t1x1 f" #FL, TH * 64, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, 1, 1, FL, 16, 1>, G>}
 #define F43F(TH, BN, TM, TN, FL) {"wino43 " #TH "x128x" #BN " t" #TM "x" #TN " f" #FL, TH * 128, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, FL>}
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
@@ -72,6 +80,12 @@ static Variant variants[] = {
     F43N(4, 64, 4), F43N(4, 64, 0),
     F43Q(4, 64, 2, 1, 260), F43Q(4, 64, 2, 1, 3844), F43N(4, 64, 32772), F43N(4, 64, 32768), F43Q(4, 64, 1, 2, 32772), F43Q(4, 64, 2, 1, 32772), F43Q(4, 32, 1, 1, 32772),
     F43Q(4, 32, 1, 1, 65540), F43N(4, 64, 65540), F43Q(4, 64, 2, 1, 65540),
+    F43Q8(8, 64, 2, 1, 32772), F43Q8(8, 64, 1, 2, 32772), F43N8(8, 64, 32772), F43Q8(8, 32, 1, 1, 65540), F43Q8(8, 32, 1, 1, 32772),
+    // persistent launches (flag 524288); + 131072: the next pair's first activation chunk requested before the epilogue, + 262144: its whole prologue
+    PQ(4, 64, 2, 1, 557060, 2), PN(4, 64, 557060, 2), PQ(4, 32, 1, 1, 589828, 4),
+    PQ(4, 64, 2, 1, 688132, 2), PN(4, 64, 688132, 2), PN(4, 64, 950276, 2),
+    PQ8(8, 64, 2, 1, 557060, 2), PN8(8, 64, 557060, 2), PQ8(8, 32, 1, 1, 589828, 4),
+    PQ8(8, 64, 2, 1, 688132, 2), PN8(8, 64, 688132, 2), PN8(8, 64, 950276, 2),
     X(4, 128, 2, 2), XA(4, 128, 2, 2, 1028), XA(4, 128, 2, 2, 2052), XA(4, 64, 2, 1, 1028), XA(4, 64, 2, 1, 2052), X(4, 64, 1, 2), X(4, 64, 2, 1), X(4, 32, 1, 1),
     S(4, 64, 4, 1, 6), S(4, 64, 4, 1, 3), S(8, 64, 4, 1, 6), S(4, 128, 2, 2, 6), S(8, 128, 4, 2, 6), S(8, 128, 4, 2, 3), S(8, 128, 2, 2, 3), S(16, 128, 4, 2, 3), S(16, 64, 4, 1, 3), S(8, 64, 2, 1, 3), S(16, 128, 4, 1, 3), S(8, 64, 4, 1, 3), S(4, 128, 2, 2, 3), S(8, 32, 4, 1, 3), S(8, 32, 4, 1, 6), S(8, 64, 2, 2, 6),
     H(8, 128, 4, 2, 4), H(8, 64, 4, 1, 4), H(8, 32, 4, 1, 4), H(4, 64, 4, 1, 4),
@@ -194,6 +208,9 @@ static Shape shapes[] = {
     {"flow_l3_c0  M=69120  C=1920->256 3x3", 8, 72, 120, 1920, 256, 3},
     {"flow_l0_c1  M=4.4M   C=32->32 3x3", 8, 576, 960, 32, 32, 3},
     {"flow_l1_c1  M=1.1M   C=64->64 3x3", 8, 288, 480, 64, 64, 3},
+    {"fusion_2_1  M=138240 C=1168->256 3x3", 4, 144, 240, 1168, 256, 3},
+    {"feat_conv5  M=276480 C=256->256 3x3", 8, 144, 240, 256, 256, 3},
+    {"fusion_0_2  M=2.2M   C=64->64 3x3", 4, 576, 960, 64, 64, 3},
 };
 
 int main(int argc, char** argv) {

@@ -333,7 +333,22 @@ def case_recursive(ref, prefix):
     return out
 
 
-CASES = {'tiny': case_tiny, '256': case_256, 'photos': case_photos, 'vimeo': case_vimeo,
+def case_recursive6(ref, prefix):
+    """BASELINE configs[4] in small: the reference's own eval/util.py:interpolate_recursively_from_memory at
+    times_to_interpolate = 6 (63 generated frames, depth-first) over Interpolator(align=64, block_shape=[2,2]) on a
+    144x176 pair (patches 72x88 -> padded to 128x128): six generations of fed-back round-off through the reference's
+    recursion / tiling / padding code.  Stored per frame: stride-4 sample + float64 row / column sums."""
+    w = W.make_synthetic_weights(O.PUBLISHED, seed=0)
+    x0, x1 = TI.frame_pair(1, 144, 176, seed=14, shift=(7, -9), fg_shift=(-5, 11))
+    it = _interpolator(ref, w, align=64, block_shape=[2, 2])
+    frames = np.stack(list(ref.util.interpolate_recursively_from_memory([x0[0], x1[0]], 6, it))).astype(np.float32)
+    assert frames.shape == (65, 144, 176, 3)
+    out = {'in_checksum': checksum(x0, x1)}
+    put(out, 'frames', frames, False)
+    return out
+
+
+CASES = {'recursive6': case_recursive6, 'tiny': case_tiny, '256': case_256, 'photos': case_photos, 'vimeo': case_vimeo,
          'recursive': case_recursive, '1080p': case_1080p}
 
 
