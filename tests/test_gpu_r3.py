@@ -315,3 +315,29 @@ def test_every_f43_tile_shape_gives_the_same_bits(published, b, h, w):
     print('F(4,3) tile shapes exercised:', sorted(used))
     assert {12, 13, 14, 16} <= used        # the Q8 tiles ran
     eng.close()
+
+
+def test_depth6_recursion_against_the_reference_recursion_code(published):
+    """The frames of the reference's OWN interpolate_recursively_from_memory at times_to_interpolate = 6 over its 2x2-tiled
+    Interpolator (tests/golden/ref_recursive6.npz, tools/make_ref_golden.py case_recursive6: 144x176 pair, patches padded
+    to 128x128) vs the device breadth-first driver behind eval/util.py on the HIP engine: all 63 generated frames, max|delta|
+    per generation printed."""
+    import golden_util as G
+    from eval import util
+    from eval.interpolator import Interpolator
+    opt, w, eng = published
+    g, prov = G.load('recursive6')
+    x0, x1 = TI.frame_pair(1, 144, 176, seed=14, shift=(7, -9), fg_shift=(-5, 11))
+    G.check_inputs(g, x0, x1)
+    it = Interpolator('', align=64, block_shape=[2, 2], engine=eng)
+    frames = np.stack(list(util.interpolate_recursively_from_memory([x0[0], x1[0]], 6, it)))
+    assert frames.shape == (65, 144, 176, 3)
+    per = {}
+    for k in range(1, 64):
+        gen = 6 - ((k & -k).bit_length() - 1)             # frame k = m * 2^(6 - gen), m odd
+        d = float(np.abs(frames[k, ::G.STRIDE, ::G.STRIDE] - g['frames.s4'][k]).max())
+        rows = float(np.abs(frames[k].astype(np.float64).sum(axis=1) - g['frames.rowsum'][k]).max() / frames.shape[2])
+        cols = float(np.abs(frames[k].astype(np.float64).sum(axis=0) - g['frames.colsum'][k]).max() / frames.shape[1])
+        per[gen] = max(per.get(gen, 0.0), d, rows, cols)
+    print(f'T = 6 vs {prov} golden (reference recursion + tiling code): max|d| per generation', {k: float(f'{v:.2e}') for k, v in sorted(per.items())})
+    assert max(per.values()) < IMAGE_TOL and np.array_equal(frames[0], x0[0]) and np.array_equal(frames[64], x1[0])

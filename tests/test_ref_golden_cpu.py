@@ -170,9 +170,32 @@ def test_recursive_driver_order_and_png_rounding(published_weights):
     assert np.array_equal(got[0], x0[0]) and np.array_equal(got[4], x1[0])
 
 
+def test_depth6_recursion_against_the_reference_recursion_code(published_weights):
+    """BASELINE configs[4] in small: the frames the reference's own interpolate_recursively_from_memory produced at
+    times_to_interpolate = 6 over its 2x2-tiled Interpolator (tools/make_ref_golden.py case_recursive6: 63 frames, 252
+    patch forwards).  The oracle follows ONE root-to-leaf path of that tree - frames 32, 16, 8, 4, 2, 1: one per generation,
+    each computed from the oracle's own previous one, 24 patch forwards - so six generations of fed-back round-off are
+    compared, not six independent forwards."""
+    from oracle import film_oracle as fo
+    g, prov = G.load('recursive6')
+    x0, x1 = TI.frame_pair(1, 144, 176, seed=14, shift=(7, -9), fg_shift=(-5, 11))
+    G.check_inputs(g, x0, x1)
+    it = fo.OracleInterpolator(published_weights, align=64, block_shape=[2, 2])
+    half = np.full((1,), 0.5, np.float32)
+    right, errs = x1, []
+    for gen, k in enumerate((32, 16, 8, 4, 2, 1), start=1):
+        right = it(x0, right, half)                       # mid(frame 0, frame 2k) = frame k
+        s4 = g['frames.s4'][k]
+        d = float(np.abs(right[0, ::G.STRIDE, ::G.STRIDE] - s4).max())
+        rows = float(np.abs(right[0].astype(np.float64).sum(axis=1) - g['frames.rowsum'][k]).max() / right.shape[2])
+        errs.append(max(d, rows))
+    print(prov, 'T = 6 path, max|d| per generation:', [float(f'{e:.2e}') for e in errs])
+    assert max(errs) < 5e-5 and tuple(g['frames.shape']) == (65, 144, 176, 3)
+
+
 def test_tensorflow_pinning_status():
     """Not a pass/fail of the code: states in the test log whether any vector here was produced by TensorFlow."""
-    cases = ['tiny', '256', 'photos', 'vimeo', '1080p', 'recursive']
+    cases = ['tiny', '256', 'photos', 'vimeo', '1080p', 'recursive', 'recursive6']
     pinned = [c for c in cases if G.pinned_by_tensorflow(c)]
     if not pinned:
         pytest.skip('parity unpinned against TensorFlow itself: tests/golden/tf_*.npz absent (no TF in this image); '
