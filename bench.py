@@ -251,6 +251,7 @@ def main():
                          'estimator (default); 2: coarse decoder levels on the side stream beside the estimator (measured slower)')
     ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
                     help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
+    ap.add_argument('--wino2d', type=int, default=None, choices=[0, 1, 2], help='engine option "wino2d" (nested Winograd kernel); default: the engine default')
     ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
     ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
     ap.add_argument('--plan-only', action='store_true',
@@ -309,6 +310,8 @@ def main():
         eng.set_option('graph', 0)
     if args.lanes != 1:
         eng.set_option('lanes', args.lanes)
+    if args.wino2d is not None:
+        eng.set_option('wino2d', args.wino2d)
     if args.precision:
         eng.set_option('precision', args.precision)
         args.no_split = True
@@ -406,12 +409,14 @@ def main():
             if o['kind'] != 'conv_mfma':
                 continue
             f = o['flops']
-            if o['tile'] & 256:
+            if o['tile'] & 8192:
+                f *= 1.0 / 3.0                                   # nested Winograd F(4,3)x x F(2,3)y: 3 multiplies per output of 9
+            elif o['tile'] & 256:
                 f *= 0.5 if o['tile'] & 2048 else 2.0 / 3.0    # Winograd F(4,3) / F(2,3) along x
             elif o['tag'].endswith(':phases'):
                 f *= 9.0 / 16.0
             exec_flops += f
-            if (o['tile'] & 256) and (o['tile'] & 2048):
+            if (o['tile'] & 256) and (o['tile'] & 2048) and not (o['tile'] & 8192):
                 dom['launches'] += 1
                 dom['ms'] += o['ms']
                 dom['executed_flops'] += f

@@ -28,6 +28,7 @@
 #include "conv_split_impl.h"
 #include "conv_wino_impl.h"
 #include "conv_wino43_impl.h"
+#include "conv_wino2d_impl.h"
 #include "conv_winox3_impl.h"
 #include "conv_foldx3_impl.h"
 #include "conv_igemm_impl.h"
@@ -126,6 +127,17 @@ static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
 }
 
 template <int F>
+static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case W2D_Q8_8x64: return conv_wino2d_launch<8, 64, F | W2D_F_ILV, 8>(p, s);
+    case W2D_Q8_8x32: return conv_wino2d_launch<8, 32, F | W2D_F_ILV, 8>(p, s);
+    case W2D_Q16_4x64: return conv_wino2d_launch<4, 64, F | W2D_F_ILV, 16>(p, s);
+    case W2D_Q16_4x32: return conv_wino2d_launch<4, 32, F | W2D_F_ILV, 16>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+template <int F>
 static hipError_t launch_winox3(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
     case WX3_4x128_T22: return conv_winox3_launch<4, 128, 2, 2, F>(p, s);
@@ -173,7 +185,11 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 
 static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = (tile & (CONV_TILE_XCD - 1)) + (((tile & CONV_TILE_EXT) && (tile & CONV_TILE_F43)) ? 16 : 0);
-  if ((p.pool_out != nullptr || p.pw_out != nullptr) && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
+  if ((p.pool_out != nullptr || p.pw_out != nullptr) && ((tile & CONV_TILE_W2D) || !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3)))) return hipErrorInvalidValue;
+  if (tile & CONV_TILE_W2D) {
+    if (p.ksize != 3 || p.pool_out != nullptr || p.pw_out != nullptr) return hipErrorInvalidValue;
+    return (tile & CONV_TILE_XCD) ? launch_wino2d<CONV_B_XCD_M>(p, shape, s) : launch_wino2d<0>(p, shape, s);
+  }
   if (tile & CONV_TILE_FOLDX3) {
     if (p.ksize != 2 || p.fold != 2) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_foldx3<CONV_B_XCD_M>(p, shape, s) : launch_foldx3<0>(p, shape, s);
@@ -204,7 +220,7 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   // split-K is implemented by conv_buf_kernel and conv_wino43_kernel only
-  const bool can_split = !(tile & (CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
+  const bool can_split = !(tile & (CONV_TILE_W2D | CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
                          (!(tile & CONV_TILE_WINO) || (tile & CONV_TILE_F43));
   if (p.ksplit > 1 && !can_split) return hipErrorInvalidValue;
   const hipError_t e = film_launch_conv_main(p, tile, s);

@@ -1,0 +1,307 @@
+// conv_wino2d_impl.h -- 3x3 Conv2D('same') + bias + leaky_relu with a NESTED Winograd transform, fp32 MFMA:
+// F(4,3) along x (as conv_wino43_impl.h) x F(2,3) along y.  Per output UNIT of 2 rows x 4 pixels and per (ci, co):
+// 4 (mu) x 6 (nu) = 24 multiplies for 8 outputs = 3 per output, where the 1-D F(4,3) form spends 18 / 4 = 4.5 and the
+// direct convolution 9: 1.5x fewer v_mfma_f32_32x32x2_f32 than conv_wino43_kernel.
+//
+//   d (4 rows x 6 pixels)  --x: F(4,3) B^T per row-->  v[r][nu]  --y: F(2,3) B^T-->  V[mu][nu]:
+//       V[0] = v[0] - v[2]     V[1] = v[1] + v[2]     V[2] = v[2] - v[1]     V[3] = v[1] - v[3]
+//   weights  U[mu][nu]: u_nu(dy) = the F(4,3) transform of kernel row dy (as in conv_wino43_impl.h), then along dy
+//       U[0] = u(0)    U[1] = ((u(0) + u(2)) + u(1)) / 2    U[2] = ((u(0) + u(2)) - u(1)) / 2    U[3] = u(2)
+//   M[mu][nu] = sum_ci V[mu][nu] U[mu][nu]  (24 independent GEMMs),  x inverse per mu (conv_wino43's y0..y3), then
+//       row 2k = (M'[0] + M'[1]) + M'[2]      row 2k+1 = (M'[1] - M'[2]) - M'[3]
+//
+// Mapping (what makes it affordable - the 2-D form was sized and rejected twice because the activation staging per MFMA
+// grows; here it does not):
+//   * the activation staging is conv_wino43_kernel's, unchanged: the x-transformed halo rows of a K chunk go to LDS once,
+//     [halo row][nu 6][quad][8] - 10 rows per 8 output rows with the 32-pixel x 8-row patch;
+//   * the y transform costs NO extra staging: a wave owns ONE mu (and 32 output channels, all six nu planes: 96 accumulator
+//     registers) and forms its A fragment as (row a) +- (row b) of that LDS image on the way into the MFMA - two
+//     ds_read_b128 and four v_fma per four MFMAs;
+//   * a (mu, channel tile) weight slab has exactly one consumer wave, so the weights skip LDS: [Cout / 32][chunk][mu][nu]
+//     [K half][32 channels][4] in memory = one fully coalesced 1 KB read per (mu, nu) step, requested a chunk ahead;
+//   * one barrier per chunk (24 MFMAs per wave); the epilogue exchanges the mu planes through LDS in four rounds.
+// fp32 throughout.  A different summation family from the 1-D kernels (not bit-identical to them).
+#pragma once
+#include "conv_buf_impl.h"
+
+enum { W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
+                              // gaps between MFMA groups) instead of sitting between the last MFMA and the barrier
+       W2D_DBG_NOB = 256,     // timing ablations (tools/conv_bench.hip only; results are wrong on purpose): no weight loads in the K loop
+       W2D_DBG_NOCOMB = 512,  // no second fragment read / no y combine
+       W2D_DBG_NOA = 1024,    // no activation staging in the K loop
+       W2D_DBG_NOBAR = 2048 };// no barrier in the K loop
+
+template <int TH, int BN, int FLAGS, int QW = 8>
+__global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_wino2d_kernel(ConvParams p) {
+  constexpr int RPT = 32 / QW;                 // patch rows of UNITS per 32-unit MFMA tile (unit = 2 rows x 4 pixels)
+  static_assert(QW == 8 || QW == 16, "quads per patch row");
+  static_assert(TH == 2 * RPT, "one 32-unit MFMA row tile per workgroup: TH = 2 * 32 / QW");
+  constexpr int NG = BN / 32, NW = 4 * NG, NT = NW * 64;
+  constexpr int HR = TH + 2;
+  constexpr int A_PLANE = QW * 8;              // floats of one nu plane of a halo row
+  constexpr int A_STAGE = HR * 6 * A_PLANE;    // floats: [hy][nu][quad][8]
+  constexpr int ITEMS = HR * QW * 2;           // (halo row, quad, 4-channel group)
+  constexpr int PXW = 4 * QW;
+  static_assert(ITEMS <= NT, "staging items");
+  constexpr unsigned OOB = 0xFFFFFFFFu;
+
+  extern __shared__ __attribute__((aligned(1024))) float smem[];  // [A0][A1]; the epilogue reuses it as the exchange buffer
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int mu = wv & 3, ng = wv >> 2;
+
+  int bx = blockIdx.x, by = blockIdx.y;
+  if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int nwg = nbx * nby;
+    const int lin = by * nbx + bx;
+    const int xcd = lin & 7, idx = lin >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int nl = base + idx;
+    bx = nl / nby;
+    by = nl - bx * nby;
+  }
+  const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
+  const int img = bx / (ntx * nty);
+  const int trem = bx - img * (ntx * nty);
+  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * PXW;
+  const int n0 = by * BN;
+
+  // ---- A staging: conv_wino43_kernel's item (halo row hy, quad tq, channel group q) on the first ITEMS threads ------------
+  const bool stager = t < ITEMS;
+  const int f = stager ? t : 0;
+  const int aq = f & 1, tq = (f >> 1) % QW, ahy = (f >> 1) / QW;
+  const int a_y = y0 - 1 + ahy, a_x = x0 - 1 + 4 * tq;
+  unsigned a_ok = 0;
+  if (stager && a_y >= 0 && a_y < p.H)
+    for (int j = 0; j < 6; ++j)
+      if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
+  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ (QW >= 16 ? ((tq >> 3) & 1) : (ahy & 1))) << 2);
+  const int scol = aq * 4;
+  unsigned a_off = 0, a_pix = 0;
+  unsigned aoffj[6];   // byte offsets of the item's six pixels (out of range where the pixel is outside the image): fixed per
+                       // segment, so that a chunk's loads need no address arithmetic and the registers stay theirs
+  conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
+  int sg = 0, c0 = 0, segC = p.seg[0].C;
+  auto setup_seg = [&]() {
+    const ConvSeg& s = p.seg[sg];
+    segC = s.C;
+    a_pix = (unsigned)s.stride * 4u;
+    int be = img + s.boff;
+    if (s.bmod && be >= s.bmod) be -= s.bmod;
+    arsrc = conv_make_rsrc(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride);
+    a_off = (unsigned)((ahy * p.W + a_x) * s.stride + scol) * 4u;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      aoffj[j] = ((a_ok >> j) & 1u) ? a_off + (unsigned)j * a_pix : OOB;
+      asm volatile("" : "+v"(aoffj[j]));   // keep it in its register (hipcc otherwise recomputes it per chunk into registers that
+                                           // are still the destination of loads in flight, and has to wait for those)
+    }
+  };
+  const int nkc = p.Ctot / 8;
+  bf4 araw[2][6];
+  bool chunk_ok = true;
+  auto load_item = [&](auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    const unsigned so = (unsigned)c0 * 4u;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) araw[SET][j] = conv_buf_load(arsrc, aoffj[j], so);
+  };
+  auto store_item = [&](int stage, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    float* As = smem + stage * A_STAGE + a_lds;
+    bf4 v[6];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const float d0 = araw[SET][0][c], d1 = araw[SET][1][c], d2 = araw[SET][2][c], d3 = araw[SET][3][c], d4 = araw[SET][4][c], d5 = araw[SET][5][c];
+      const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+      const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+      v[0][c] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+      v[1][c] = t1 + t2;
+      v[2][c] = t1 - t2;
+      v[3][c] = t3 + t4;
+      v[4][c] = t3 - t4;
+      v[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    }
+#pragma unroll
+    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<bf4*>(As + nu * A_PLANE) = v[nu];
+  };
+  auto next_chunk = [&](int kc_next) {
+    if (kc_next >= nkc) {   // past the last chunk: the remaining (prefetch) loads read nothing
+      chunk_ok = false;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) aoffj[j] = OOB;
+      return;
+    }
+    c0 += 8;
+    if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
+  };
+
+  // ---- weights: [Cout / 32][chunk][mu][nu][K half][32][4] floats; this wave reads slab (ct, kc, mu): 6 x 1 KB -----------------
+  const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
+  const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
+  const int ct = n0 / 32 + ng;
+  bf4 fbg[2][6];
+  auto load_b = [&](int kc, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
+    const unsigned so = (unsigned)(((ct * nkc + (kc < nkc ? kc : nkc - 1)) * 4 + mu) * 6) * 1024u;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fbg[SET][j] = conv_buf_load(brsrc, bvoff, so + (unsigned)j * 1024u);   // one address register for the six loads
+  };
+
+  f32x16 acc[6];
+#pragma unroll
+  for (int v = 0; v < 6; ++v)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+
+  // ---- A fragments: lane (unit row ur, quad lq, K half) reads halo rows 2 ur + ra and 2 ur + rb and combines them ----------
+  //   mu 0: v[0] - v[2]   mu 1: v[1] + v[2]   mu 2: v[2] - v[1]   mu 3: v[1] - v[3]
+  const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
+  constexpr int A_STAGE4 = A_STAGE / 4;
+  const int ur = l31 / QW, lq = l31 % QW;
+  const int ra = mu == 0 ? 0 : mu == 2 ? 2 : 1, rb = mu == 0 ? 2 : mu == 1 ? 2 : mu == 2 ? 1 : 3;
+  const float sgn = mu == 1 ? 1.f : -1.f;
+  auto row_ad = [&](int hy) {   // float4 index of (halo row hy, nu 0, quad lq, this lane's K half)
+    const int sw = QW >= 16 ? ((lq >> 3) & 1) : (hy & 1);
+    return ((hy * 6) * QW + lq) * 2 + (half ^ sw);
+  };
+  const int ad_a = row_ad(2 * ur + ra), ad_b = row_ad(2 * ur + rb);
+
+  using C0 = std::integral_constant<int, 0>;
+  using C1 = std::integral_constant<int, 1>;
+  // Every thread issues the activation loads - threads without an item have a_ok = 0, i.e. out-of-range offsets that
+  // return zero without touching memory - so that all waves have the SAME number of loads in flight: with the loads under
+  // `if (stager)` the compiler has to place one s_waitcnt vmcnt(n) valid for both paths, and the staging waves then wait
+  // for the weight loads they issued a moment ago (a full L2 latency per chunk)
+  setup_seg();
+  load_item(C0{});
+  load_b(0, C0{});
+  // (the chunk / segment state - c0, the buffer resource - advances on EVERY thread: kept uniform it lives in scalar
+  // registers; advanced under `if (stager)` it becomes a per-lane value and every buffer load turns into a waterfall loop)
+  next_chunk(1);
+  load_item(C1{});
+  if (stager) store_item(0, C0{});
+  next_chunk(2);
+  __syncthreads();
+
+  auto chunk = [&](int kc, auto par_c) {
+    constexpr int PAR = decltype(par_c)::value;
+    const int sa = (kc & 1) * A_STAGE4;
+    if constexpr ((FLAGS & W2D_DBG_NOB) == 0) load_b(kc + 1, std::integral_constant<int, 1 - PAR>{});
+    if constexpr ((FLAGS & W2D_DBG_NOA) == 0) load_item(par_c);   // chunk kc + 2 into the register set chunk kc came from
+    __builtin_amdgcn_sched_barrier(0);   // the twelve requests of the chunk go out first, in this order (the s_waitcnt counts below rely on it)
+    bf4 fa[2], fb2[2];
+    bf4 sv[6];   // W2D_F_ILV: the item of chunk kc + 1, transformed two channels per nu step
+    constexpr bool ILV = (FLAGS & W2D_F_ILV) != 0 && (FLAGS & W2D_DBG_NOA) == 0;
+    auto xform = [&](int c) {
+      constexpr int SET = 1 - PAR;
+      const float d0 = araw[SET][0][c], d1 = araw[SET][1][c], d2 = araw[SET][2][c], d3 = araw[SET][3][c], d4 = araw[SET][4][c], d5 = araw[SET][5][c];
+      const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+      const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
+      sv[0][c] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+      sv[1][c] = t1 + t2;
+      sv[2][c] = t1 - t2;
+      sv[3][c] = t3 + t4;
+      sv[4][c] = t3 - t4;
+      sv[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+    };
+    float* const As_next = smem + ((kc + 1) & 1) * A_STAGE + a_lds;
+    fa[0] = smem4[sa + ad_a];
+    constexpr bool COMB = (FLAGS & W2D_DBG_NOCOMB) == 0;
+    if constexpr (COMB) fb2[0] = smem4[sa + ad_b];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      if (j + 1 < 6) {
+        fa[(j + 1) & 1] = smem4[sa + ad_a + (j + 1) * (QW * 2)];
+        if constexpr (COMB) fb2[(j + 1) & 1] = smem4[sa + ad_b + (j + 1) * (QW * 2)];
+      }
+      bf4 a;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) a[k] = COMB ? __builtin_fmaf(sgn, fb2[j & 1][k], fa[j & 1][k]) : fa[j & 1][k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], fbg[PAR][j][k], acc[j], 0, 0, 0);
+      if constexpr (ILV) {
+        if (stager) {
+          if (j == 0) { xform(0); xform(1); }
+          if (j == 1) { xform(2); xform(3); }
+          if (j == 2) {
+#pragma unroll
+            for (int nu = 0; nu < 3; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
+          }
+          if (j == 3) {
+#pragma unroll
+            for (int nu = 3; nu < 6; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (!ILV && (FLAGS & W2D_DBG_NOA) == 0) { if (stager) store_item((kc + 1) & 1, std::integral_constant<int, 1 - PAR>{}); }   // chunk kc + 1
+    if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
+    next_chunk(kc + 3);
+  };
+  for (int kc = 0; kc < nkc; kc += 2) {
+    chunk(kc, C0{});
+    if (kc + 1 < nkc) chunk(kc + 1, C1{});
+  }
+
+  // ---- epilogue: x inverse in registers (conv_wino43's y0..y3 per mu), then the y inverse across the four mu waves of a
+  // channel tile through LDS, one x position per round: waves mu = 1, 2 publish, mu = 0 forms row 2k = (m0 + m1) + m2,
+  // mu = 3 forms row 2k + 1 = (m1 - m2) - m3.  C/D layout of the 32x32 MFMA: col = lane & 31 (cout), row = (r&3) + 8*(r>>2)
+  // + 4*(lane>>5) = unit.
+  float* const xbuf = smem;                                  // [ng][which: mu 1 / mu 2][16 regs][64 lanes]
+  const int n = n0 + ng * 32 + l31;
+  const float bv = p.bias[n];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+      o[r] = j == 0 ? ((m0 + m1) + m2) + (m3 + m4) : j == 1 ? (m1 - m2) + 2.f * (m3 - m4) : j == 2 ? (m1 + m2) + 4.f * (m3 + m4)
+                                                                                          : (m1 - m2) + (8.f * (m3 - m4) + m5);
+    }
+    if (j) __syncthreads();            // the previous round has been consumed
+    if (mu == 1 || mu == 2) {
+      float* give = xbuf + ((ng * 2 + (mu - 1)) * 16) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) give[r * 64] = o[r];
+    }
+    __syncthreads();
+    if (mu == 0 || mu == 3) {
+      const float* t1 = xbuf + ((ng * 2 + 0) * 16) * 64 + lane;
+      const float* t2 = xbuf + ((ng * 2 + 1) * 16) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float m1 = t1[r * 64], m2 = t2[r * 64];
+        float v = mu == 0 ? (o[r] + m1) + m2 : (m1 - m2) - o[r];
+        const int unit = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int y = y0 + 2 * (unit / QW) + (mu == 3 ? 1 : 0);
+        const int x = x0 + 4 * (unit % QW) + j;
+        v += bv;
+        if (p.leaky) v = v > 0.f ? v : 0.2f * v;
+        if (y < p.H && x < p.W) p.out[(((size_t)img * p.H + y) * p.W + x) * p.ostride + n] = v;
+      }
+    }
+  }
+}
+
+template <int TH, int BN, int FLAGS, int QW = 8>
+hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
+  constexpr size_t a_bytes = 2 * (size_t)(TH + 2) * 6 * QW * 8 * sizeof(float);
+  constexpr size_t x_bytes = (size_t)(BN / 32) * 2 * 16 * 64 * sizeof(float);
+  constexpr size_t lds = a_bytes > x_bytes ? a_bytes : x_bytes;
+  constexpr int NT = 4 * (BN / 32) * 64;
+  static_assert(lds <= 64 * 1024, "LDS");
+  if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 8 || p.Cout % BN) return hipErrorInvalidValue;
+  auto kern = conv_wino2d_kernel<TH, BN, FLAGS, QW>;
+  const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
+  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
+  return hipGetLastError();
+}

@@ -78,8 +78,10 @@ struct OpDesc {
   int64_t ww_off = -1;                // conv: the layer's Winograd F(2,3) weight copy
   int64_t wx_off = -1;                // conv: ... and its 2-plane bf16 split (precision mode bf16x3, conv_winox3_kernel)
   int64_t w43_off = -1;               // conv: the layer's Winograd F(4,3) weight copy (conv_wino43_kernel)
+  int64_t w2d_off = -1;               // conv: the layer's nested F(4,3) x F(2,3) weight copy (conv_wino2d_kernel; deep-K layers only)
   int64_t wfx_off = -1;               // conv: phase-summed weights of a folded 2x2 layer as bf16 hi / mid (conv_foldx3_kernel)
-  int wino = 0;                       // conv: 1 = runs on conv_wino_kernel, 2 = on conv_winox3_kernel (precision bf16x3)
+  int wino = 0;                       // conv: 1 = runs on conv_wino_kernel, 2 = on conv_winox3_kernel (precision bf16x3), 3 = conv_wino43_kernel,
+                                      //       4 = conv_wino2d_kernel (nested F(4,3) x F(2,3))
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
   int lane = 0;                       // graph replay: 0 = main stream, 1 = side stream (small / HBM-bound work)
   std::vector<int> xdeps;             // ops on the OTHER lane this op must wait for (from the buffer overlap analysis)
@@ -114,12 +116,18 @@ struct LayerPack {
   int64_t wfx_off = -1;      // 2x2 layers after an upsample: the phase-summed weights as bf16 hi / mid for conv_foldx3_kernel,
                              //     [Cout][ctot/16][9 (tap, phase) steps][plane][16] bf16
   int64_t w43_off = -1;      // ... the F(4,3)-along-x transformed copy for conv_wino43_kernel, [Cout][ctot/8][3 dy][6 nu][8]
+  int64_t w2d_off = -1;      // deep-K layers (has_w2d): the nested F(4,3)x x F(2,3)y copy for conv_wino2d_kernel,
+                             //     [Cout/32][ctot/8][mu 4][nu 6][K half][32][4] (24 values per (ci, co): 2.67x the kernel)
   int64_t wx_off = -1;       // ... and the transformed copy split into bf16 hi / mid for conv_winox3_kernel,
                              //     [Cout][ctot/16][dy][j][h][plane][16] bf16 (nu = 2h + j)
   int64_t ws_off = -1;       // ... and the bf16x6 copy for conv_halo_split_kernel, [Cout][ctot/16][9][3][16] bf16
                              //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
   bool has_fold() const { return kmajor() && kh == 2 && kw == 2; }
+  // conv_wino2d_kernel against the best 1-D F(4,3) tile of the same run (tools/conv_bench.hip, profiles/r03_conv_bench_w2d.log):
+  // 1.12-1.24x at K = 384 ... 2448, 1.06x at 256 -> 256, 1.02x at 208 -> 64, 1.17x at 128 -> 32 (where the 1-D kernel's
+  // 32-channel tile is weak), 0.97x at 128 -> 128, 0.85x at K = 64 (its activation staging per MFMA is 1.5x the 1-D kernel's)
+  bool has_w2d() const { return has_halo() && (ctot() >= 208 || (ctot() >= 128 && cout == 32)); }
   int ctot() const { return (int)perm.size(); }
   int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
 };
@@ -183,6 +191,7 @@ struct film_handle {
                           // worse than one; kept as a tested option, not the default)
   hipStream_t stream2 = nullptr;
   int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs; 2: bf16x3
+  int opt_wino2d = 1;     // nested Winograd kernel: 0 never, 1 (default) the deep-K layers of the large levels, 2 every layer that has the copy (tests)
   int opt_w43_shape = -1; // tests: >= 0 = every conv_wino43_kernel op that can run this Wino43Tile shape does (instead of the autotuned one)
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile
@@ -339,6 +348,7 @@ void build_layers(film_t* h) {
     L.b_off = off; off += L.cout; al();
     if (L.has_fold()) { L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; al(); }
     if (L.has_halo()) { L.w43_off = off; off += L.packed_rows() * L.cout / 9 * 18; al(); }
+    if (L.has_w2d()) { L.w2d_off = off; off += L.packed_rows() * L.cout / 9 * 24; al(); }
   }
   h->group_end[0] = off;
   for (auto& L : h->layers)
@@ -369,6 +379,7 @@ struct Planner {
 
   bool bad = false;
   std::string bad_msg;
+  bool w2d_ok = true;   // cleared by the caller for a layer whose epilogue fusion (average pool) only conv_wino43_kernel has
 
   int add_buffer(const std::string& name, int N, int H, int W, int C) {
     Buffer b{name, cursor, N, H, W, C, (int64_t)N * H * W * C};
@@ -432,7 +443,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off; op.w43_off = L.w43_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off; op.w43_off = L.w43_off; op.w2d_off = L.w2d_off;
     if (h->opt_fold && L.wf_off >= 0 && op.nseg == 1 && segs[0].up && !(H & 1) && !(W & 1)) {
       // nearest x2 + 2x2 'same' conv == four phase convolutions on the low-resolution input: kernel tap (dy, dx) of
       // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
@@ -500,9 +511,16 @@ struct Planner {
     // fills its 64-pixel patches (the Q16 tiles; at most 15 % of the last patch of a row empty: 960 ... 60, 448, 256 ...); wino = 3.  "winograd" = 2 / 3 force
     // F(2,3) / F(4,3) onto every eligible layer (tests).
     if (op.wino == 1 && h->opt_wino != 2 && w43_width) op.wino = 3;
+    // Nested F(4,3)x x F(2,3)y (conv_wino2d_kernel, 1.5x fewer MFMAs again): the deep-K layers (K >= 384: the first layer of
+    // every flow predictor but level 0's, the wide layer of every decoder level but level 0's, cfeat_conv_7) on levels large
+    // enough to fill the chip without split-K.  A family of its own (a function of the layer and the level size only).
+    if (L.w2d_off >= 0 && w2d_ok && !any_up && h->opt_precision == 0 &&
+        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && op.wino == 3 && h->opt_wino == 1 && px >= 8192)))
+      op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
-    op.tile = op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_BG) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
+    op.tile = op.wino == 4 ? ((L.cout % 64 == 0 ? W2D_Q8_8x64 : W2D_Q8_8x32) | CONV_TILE_W2D | CONV_TILE_XCD)
+              : op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_BG) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
               : op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)
               : op.split ? ((L.cout % 128 == 0 ? HALO_8x128 : L.cout % 64 == 0 ? HALO_4x64 : HALO_8x32) | CONV_TILE_SPLIT | (op.split == 2 ? CONV_TILE_X3 : 0) | CONV_TILE_XCD)
@@ -662,7 +680,9 @@ struct Planner {
         }
         SegDesc s1; s1.v = tmp;
         View dst = view(feat[lv], 0, slot_offset(c, j), k);
+        w2d_ok = !(j < n - 1 && (h->opt_fuse & 8));   // a pooled stage keeps the kernel that fuses the pool into its epilogue
         conv(tg, w1, {s1}, dst, N2, HL(lv), WL(lv), true);
+        w2d_ok = true;
         if (j < n - 1) {
           OpDesc& cv = P->ops.back();
           if ((h->opt_fuse & 8) && cv.kind == OP_CONV && cv.wino == 3 && cv.ksplit <= 1 && !(HL(lv) & 1) && !(WL(lv) & 1)) {
@@ -927,7 +947,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
         p.seg[i].boff = op.seg[i].boff; p.seg[i].bmod = op.seg[i].bmod; p.seg[i].up = op.seg[i].up;
       }
       p.ksize = op.ksize;
-      p.w = wts + ((op.tile & CONV_TILE_FOLDX3) ? op.wfx_off
+      p.w = wts + ((op.tile & CONV_TILE_W2D) ? op.w2d_off : (op.tile & CONV_TILE_FOLDX3) ? op.wfx_off
                    : (op.tile & CONV_TILE_WINO) ? ((op.tile & CONV_TILE_X3) ? op.wx_off : (op.tile & CONV_TILE_F43) ? op.w43_off : op.ww_off) : (op.tile & CONV_TILE_SPLIT) ? op.ws_off
                    : (op.tile & CONV_TILE_HALO) ? op.wh_off : op.w_off);
       p.bias = wts + op.b_off;
@@ -1061,6 +1081,13 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
   return out;
 }
 
+std::vector<int> wino2d_candidates(int Cout) {
+  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W2D_Q8_8x64, W2D_Q8_8x32, W2D_Q16_4x64, W2D_Q16_4x32} : std::vector<int>{W2D_Q8_8x32, W2D_Q16_4x32};
+  std::vector<int> out;
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> foldx3_candidates(int Cout) {
   std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{FX3_4x64, FX3_8x64, FX3_4x128} : std::vector<int>{FX3_4x64, FX3_8x64};
   std::vector<int> out;
@@ -1107,7 +1134,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
-  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
   if (op.c3) {
     // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
     // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
@@ -1310,7 +1337,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"w43_off\":" << op.w43_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
+      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"w43_off\":" << op.w43_off << ",\"w2d_off\":" << op.w2d_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
@@ -1572,6 +1599,41 @@ static void pack_layer_group(film_t* h, const LayerPack& L, int group, int co0, 
         df += kph * L.cout;
       }
   }
+  // ---- nested Winograd copy (group 0, deep-K layers): U[mu][nu] = the F(2,3) transform along dy of the F(4,3)-transformed
+  // kernel rows u_nu(dy) (the same u as the w43 copy), [Cout/32][chunk8][mu 4][nu 6][K half][32][4]
+  if (group == 0 && L.w2d_off >= 0) {
+    float* d2 = base + L.w2d_off;
+    const size_t nk8 = (size_t)ct / 8;
+    for (size_t kc = 0; kc < nk8; ++kc) {
+      const float* rows[3][3][8];
+      for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx)
+          for (int j = 0; j < 8; ++j) {
+            const int ref = L.perm[kc * 8 + j];
+            rows[dy][dx][j] = ref < 0 ? nullptr : src + ((size_t)(dy * 3 + dx) * L.cin + ref) * L.cout;
+          }
+      for (int co = co0; co < co1; ++co)
+        for (int j = 0; j < 8; ++j) {
+          float u[3][6];
+          for (int dy = 0; dy < 3; ++dy) {
+            const float g0 = rows[dy][0][j] ? rows[dy][0][j][co] : 0.f, g1 = rows[dy][1][j] ? rows[dy][1][j][co] : 0.f,
+                        g2 = rows[dy][2][j] ? rows[dy][2][j][co] : 0.f;
+            const float e = g0 * (1.f / 24.f) + g2 * (1.f / 6.f), o = g1 * (1.f / 12.f);
+            u[dy][0] = g0 * 0.25f;
+            u[dy][1] = -((g0 + g2) + g1) * (1.f / 6.f);
+            u[dy][2] = -((g0 + g2) - g1) * (1.f / 6.f);
+            u[dy][3] = e + o;
+            u[dy][4] = e - o;
+            u[dy][5] = g2;
+          }
+          for (int nu = 0; nu < 6; ++nu) {
+            const float U[4] = {u[0][nu], ((u[0][nu] + u[2][nu]) + u[1][nu]) * 0.5f, ((u[0][nu] + u[2][nu]) - u[1][nu]) * 0.5f, u[2][nu]};
+            for (int mu = 0; mu < 4; ++mu)
+              d2[(((((size_t)(co / 32) * nk8 + kc) * 4 + mu) * 6 + nu) * 2 + j / 4) * 128 + (co % 32) * 4 + j % 4] = U[mu];
+          }
+        }
+    }
+  }
   // ---- Winograd copies along x: F(4,3) [Cout][chunk8][dy][nu 6][8] (group 0), F(2,3) [Cout][chunk8][nu*3+dy][8]
   // (u0 = g0, u1 = ((g0+g2)+g1)/2, u2 = ((g0+g2)-g1)/2, u3 = g2; group 1) and its bf16 hi / mid planes (group 3)
   if (L.ww_off >= 0 && (group == 0 || group == 1 || group == 3)) {
@@ -1826,6 +1888,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->opt_lanes = (int)value;
     }
   }
+  else if (!strcmp(key, "wino2d")) {
+    if (value < 0 || value > 2) return fail(h, FILM_ERR_INVALID, "wino2d: 0, 1 or 2");
+    if ((int)value != h->opt_wino2d) {  // plans carry the kernel choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_wino2d = (int)value;
+    }
+  }
   else if (!strcmp(key, "w43_shape")) {
     if (value < -1 || value > 31) return fail(h, FILM_ERR_INVALID, "w43_shape: -1 (autotuned) or a Wino43Tile shape index");
     if ((int)value != h->opt_w43_shape) {  // plans carry the tile choice: drop them
@@ -1910,7 +1982,7 @@ namespace {
 int64_t limited_buffer_bytes(const Plan* P) {
   int64_t mx = 1;
   for (const OpDesc& op : P->ops) {
-    if (op.kind != OP_CONV || op.wino == 3) continue;
+    if (op.kind != OP_CONV || op.wino == 3 || op.wino == 4) continue;
     for (int i = 0; i < op.nseg; ++i) mx = std::max(mx, P->bufs[op.seg[i].v.buf].floats * (int64_t)sizeof(float));
   }
   return mx;

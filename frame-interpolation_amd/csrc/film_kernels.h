@@ -201,6 +201,8 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                                       weights [Cout][chunk][dy][j][h][plane][16] bf16 */,
                 CONV_TILE_F43 = 2048 /* with CONV_TILE_WINO: conv_wino43_kernel (F(4,3) along x, fp32): shape index = Wino43Tile,
                                         weights [Cout][chunk of 8][dy][nu 6][8] */,
+                CONV_TILE_W2D = 8192 /* conv_wino2d_kernel (nested F(4,3)x x F(2,3)y, fp32): shape index = Wino2dTile, weights
+                                        [Cout/32][chunk of 8][mu 4][nu 6][K half][32][4] */,
                 CONV_TILE_EXT = 4096 /* conv_wino43_kernel: shape index = (tile & 15) + 16 */,
                 CONV_TILE_FOLDX3 = 1024 /* conv_foldx3_kernel (precision mode bf16x3, folded upsample + 2x2): shape index =
                                            FoldX3Tile, weights [Cout][chunk][9 (tap, phase) steps][plane][16] bf16 */ };
@@ -221,6 +223,9 @@ enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_
                   /* ids >= 16 carry CONV_TILE_EXT in the tile id (shape = (tile & 15) + 16).  The 32-channel Q8 tile WITH the
                      weight ring: 48 KB of LDS, 152 VGPRs -> three workgroups per CU (flow level 0 conv_0: -7 % against the BG tile) */
                   W43_Q8_8x32_T11_P2 = 16 };
+// conv_wino2d_kernel tiles (CONV_TILE_W2D): one 32-unit MFMA row tile (unit = 2 rows x 4 pixels) x output channels; Q8 = 8 rows x
+// 32 pixels, Q16 = 4 rows x 64 pixels; 64 channels = 8 waves (one workgroup per CU), 32 channels = 4 waves (two per CU)
+enum Wino2dTile { W2D_Q8_8x64 = 0, W2D_Q8_8x32 = 1, W2D_Q16_4x64 = 2, W2D_Q16_4x32 = 3 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

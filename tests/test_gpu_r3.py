@@ -341,3 +341,47 @@ def test_depth6_recursion_against_the_reference_recursion_code(published):
         per[gen] = max(per.get(gen, 0.0), d, rows, cols)
     print(f'T = 6 vs {prov} golden (reference recursion + tiling code): max|d| per generation', {k: float(f'{v:.2e}') for k, v in sorted(per.items())})
     assert max(per.values()) < IMAGE_TOL and np.array_equal(frames[0], x0[0]) and np.array_equal(frames[64], x1[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# conv_wino2d_kernel: nested Winograd F(4,3)x x F(2,3)y
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 128, 64), (1, 64, 192), (1, 128, 320), (1, 192, 448)])
+def test_nested_winograd_kernel_on_every_level(published, b, h, w):
+    """"wino2d" = 2 forces conv_wino2d_kernel onto every layer that has the nested copy (K >= 208 or 128 -> 32: flow conv_0 of
+    every level, the deep flow / decoder / sub-extractor layers) on EVERY level: ragged patches (W, H below one 32 x 8 / 64 x 4 patch, odd
+    unit rows cut by the bottom edge), two-segment inputs with batch remaps (flow conv_0 reads [features | warped]),
+    three-segment decoder inputs - stage-by-stage parity with the oracle, every tile shape in turn (same bits)."""
+    from test_gpu_parity import _check_stages
+    from film_hip.engine import FilmEngine
+    opt, wts, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(wts)
+    eng.set_option('wino2d', 2)
+    plan = eng.plan(b, h, w)
+    n2d = sum(1 for op in plan['ops'] if op.get('wino') == 4)
+    assert n2d >= 12, n2d
+    x0, x1 = TI.frame_pair(b, h, w, seed=61 + h + w)
+    got, _ = _check_stages(eng, opt, wts, x0, x1)
+    eng.set_option('wino2d', 0)
+    assert sum(1 for op in eng.plan(b, h, w)['ops'] if op.get('wino') == 4) == 0
+    base = eng.forward(x0, x1)
+    print(f'wino2d everywhere vs none: max|d| {float(np.abs(got - base).max()):.2e} ({n2d} ops)')
+    eng.close()
+
+
+def test_default_plan_uses_the_nested_kernel_on_the_deep_layers_of_a_1080p_tile(published):
+    """The default plan of a 960x576 tile: conv_wino2d_kernel on the deep-K layers (K >= 208, or 128 -> 32) of the levels with >= 8192 pixels, and
+    the image stays within the usual distance of the plan without it (the tile is oracle-checked in test_gpu_configs)."""
+    opt, w, eng = published
+    plan = eng.plan(1, 576, 960)
+    w2d = [(o['tag'], o['H'], o['W'], o['Ctot']) for o in plan['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4]
+    assert len(w2d) >= 10 and all(k >= 128 and hh * ww >= 8192 for _, hh, ww, k in w2d), w2d
+    x0, x1 = TI.frame_pair(1, 576, 960, seed=2)
+    a = eng.forward(x0, x1)
+    eng.set_option('wino2d', 0)
+    b0 = eng.forward(x0, x1)
+    eng.set_option('wino2d', 1)
+    d = float(np.abs(a - b0).max())
+    print(f'960x576 tile, default plan with vs without conv_wino2d_kernel: max|d| {d:.2e}')
+    assert d < 5e-5

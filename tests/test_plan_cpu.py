@@ -181,11 +181,18 @@ def test_plan_interpreter_matches_oracle_published_64(published_packed):
     assert abs(flops / (64 * 64) - 4246240.6875) / 4246240.6875 < 1e-5
     warp_bytes = sum(op['bytes'] for op in plan['ops'] if op['kind'] == 'warp')
     assert abs(warp_bytes / (64 * 64) - 5201.58) / 5201.58 < 1e-3
-    # "lanes" = 3: the op order of large frames (coarse decoder levels emitted right behind the aligned levels they read,
-    # on the side lane) at this small size - same ops, same bits through the interpreter
+    # "wino2d" = 2 (every layer that has the nested-Winograd copy runs conv_wino2d_kernel; the interpreter checked the packed
+    # [mu][nu] copy of those layers above) AND "lanes" = 3 (the op order of option "lanes" = 2 - coarse decoder levels emitted
+    # right behind the aligned levels they read, on the side lane - at this small size) in ONE more interpreter run: same ops,
+    # another order, another kernel family; the interpreter's arithmetic does not depend on the family -> same bits
+    assert not any(o['wino'] == 4 for o in plan['ops'] if o['kind'] == 'conv_mfma')      # default rule: large levels only
+    eng.set_option('wino2d', 2)
     eng.set_option('lanes', 3)
     plan3 = eng.plan(1, 64, 64)
     eng.set_option('lanes', 1)
+    eng.set_option('wino2d', 1)
+    w2d_ops = [o for o in plan3['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4]
+    assert len(w2d_ops) >= 8 and all(o['w2d_off'] >= 0 and (o['tile'] & 8192) for o in w2d_ops)
     tags, tags3 = [o['tag'] for o in plan['ops']], [o['tag'] for o in plan3['ops']]
     assert sorted(tags) == sorted(tags3) and tags != tags3
     assert {o['lane'] for o in plan3['ops'] if o['tag'].startswith(('fusion_l3', 'fusion_l2'))} == {1}
@@ -201,7 +208,7 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
     (fold with split = 2) on the decoder's large upsample + 2x2 layers; tile ids carry the matching flags."""
     from film_hip.engine import FilmEngine, FilmError
     from film_hip.options import PUBLISHED
-    WINO, SPLIT, X3, FOLDX3, F43 = 256, 128, 512, 1024, 2048
+    WINO, SPLIT, X3, FOLDX3, F43, W2D = 256, 128, 512, 1024, 2048, 8192
     eng = FilmEngine(PUBLISHED, device=-1)
     fam = {}
     for mode in (0, 1, 2):
@@ -213,12 +220,15 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
             for op in ops:
                 t = op['tile']
                 assert bool(t & FOLDX3) == (op['fold'] == 2 and op['split'] == 2)
-                assert bool(t & WINO) == (op['wino'] != 0) and bool(t & SPLIT) == (op['split'] != 0 and not op['fold'])
+                assert bool(t & WINO) == (op['wino'] in (1, 2, 3)) and bool(t & SPLIT) == (op['split'] != 0 and not op['fold'])
+                assert bool(t & W2D) == (op['wino'] == 4) and (op['wino'] != 4 or (op['Ctot'] >= 128 and op['H'] * op['W'] >= 8192))
                 assert bool(t & X3) == (op['wino'] == 2 or (op['split'] == 2 and not op['fold']))
                 assert bool(t & F43) == (op['wino'] == 3)
         assert per_batch[0] == per_batch[1]
         fam[mode] = per_batch[0]
-    assert all(s == 0 and w in (0, 1, 3) for _, s, w, _ in fam[0]) and any(w == 3 for _, _, w, _ in fam[0])
+    assert all(s == 0 and w in (0, 1, 3, 4) for _, s, w, _ in fam[0]) and any(w == 3 for _, _, w, _ in fam[0])
+    assert any(w == 4 for _, _, w, _ in fam[0])      # the nested-Winograd family: deep-K layers of the 128x224 level (mode 0 only)
+    assert not any(w == 4 for m in (1, 2) for _, _, w, _ in fam[m])
     assert any(s == 1 for _, s, _, _ in fam[1]) and all(w == 0 for _, s, w, _ in fam[1] if s)
     assert any(w == 2 for _, _, w, _ in fam[2]) and any(s == 2 and not f for _, s, _, f in fam[2])
     assert any(s == 2 and f == 2 for _, s, _, f in fam[2])
@@ -378,9 +388,9 @@ def test_untiled_4k_frame_only_f43_layers_read_the_buffers_above_4gib():
             continue
         for sg in op['segs']:
             if size[sg['v']['buf']] > lim:
-                assert op['wino'] == 3, (op['tag'], sg['v']['buf'])
+                assert op['wino'] in (3, 4), (op['tag'], sg['v']['buf'])     # conv_wino43_kernel / conv_wino2d_kernel: patch-relative offsets
                 big_readers += 1
-            elif op['wino'] != 3:
+            elif op['wino'] not in (3, 4):
                 assert size[sg['v']['buf']] <= plan['offset32_buffer_bytes']
     assert big_readers >= 5
     # 8K untiled: a direct-convolution layer would have to read more than 4 GiB -> refused (tile it)

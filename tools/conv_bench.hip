@@ -17,6 +17,7 @@
 #include "../frame-interpolation_amd/csrc/conv_split_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_winox3_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino43_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_wino2d_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_buf_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_halo_impl.h"
@@ -70,6 +71,7 @@ hipError_t persist_launch(const ConvParams& p, hipStream_t s) { ConvParams q = p
 #define PN8(TH, BN, FL, G) {"wino43 q8 nh1 pers" #G " " #TH "x32x" #BN " t1x1 f" #FL, TH * 32, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, 1, 1, FL, 8, 1>, G>}
 #define PQ(TH, BN, TM, TN, FL, G) {"wino43 q16 pers" #G " " #TH "x64x" #BN " t" #TM "x" #TN " f" #FL, TH * 64, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, TM, TN, FL, 16>, G>}
 #define PN(TH, BN, FL, G) {"wino43 q16 nh1 pers" #G " " #TH "x64x" #BN " t1x1 f" #FL, TH * 64, BN, 8, 7, persist_launch<conv_wino43_launch<TH, BN, 1, 1, FL, 16, 1>, G>}
+#define W2D(TH, BN, FL, QW) {"wino2d q" #QW " " #TH "x" #BN " f" #FL, TH * 4 * QW, BN, 8, 8, conv_wino2d_launch<TH, BN, FL, QW>}
 #define F43F(TH, BN, TM, TN, FL) {"wino43 " #TH "x128x" #BN " t" #TM "x" #TN " f" #FL, TH * 128, BN, 8, 7, conv_wino43_launch<TH, BN, TM, TN, FL>}
 #define S(TH, BN, WM, WN, NP) {"split" #NP " " #TH "x32x" #BN " w" #WM "x" #WN " f4", TH * 32, BN, 16, 3, conv_halo_split_launch<TH, BN, WM, WN, NP, 4>}
 static Variant variants[] = {
@@ -81,6 +83,9 @@ static Variant variants[] = {
     F43Q(4, 64, 2, 1, 260), F43Q(4, 64, 2, 1, 3844), F43N(4, 64, 32772), F43N(4, 64, 32768), F43Q(4, 64, 1, 2, 32772), F43Q(4, 64, 2, 1, 32772), F43Q(4, 32, 1, 1, 32772),
     F43Q(4, 32, 1, 1, 65540), F43N(4, 64, 65540), F43Q(4, 64, 2, 1, 65540),
     F43Q8(8, 64, 2, 1, 32772), F43Q8(8, 64, 1, 2, 32772), F43N8(8, 64, 32772), F43Q8(8, 32, 1, 1, 65540), F43Q8(8, 32, 1, 1, 32772),
+    W2D(8, 64, 4, 8), W2D(8, 32, 4, 8), W2D(4, 64, 4, 16), W2D(4, 32, 4, 16), W2D(8, 64, 0, 8),
+    W2D(8, 64, 68, 8), W2D(8, 32, 68, 8), W2D(4, 64, 68, 16), W2D(4, 32, 68, 16),
+    W2D(8, 64, 260, 8), W2D(8, 64, 516, 8), W2D(8, 64, 1028, 8), W2D(8, 64, 2052, 8), W2D(8, 64, 3844, 8), W2D(8, 32, 260, 8), W2D(8, 32, 516, 8), W2D(8, 32, 1028, 8), W2D(8, 32, 3844, 8),
     // persistent launches (flag 524288); + 131072: the next pair's first activation chunk requested before the epilogue, + 262144: its whole prologue
     PQ(4, 64, 2, 1, 557060, 2), PN(4, 64, 557060, 2), PQ(4, 32, 1, 1, 589828, 4),
     PQ(4, 64, 2, 1, 688132, 2), PN(4, 64, 688132, 2), PN(4, 64, 950276, 2),
@@ -181,6 +186,29 @@ __global__ void pack_wino43_kernel(const float* src, float* dst, int C, int N) {
     dst[((((size_t)n * (C / 8) + c / 8) * 3 + dy) * 6 + nu) * 8 + c % 8] = u[nu];
 }
 
+// [tap*C + c][N] -> [N/32][chunk8][mu 4][nu 6][K half][32][4]: F(4,3) along x, then F(2,3) along y (conv_wino2d_impl.h)
+__global__ void pack_wino2d_kernel(const float* src, float* dst, int C, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)C * N) return;
+  const int n = (int)(i % N), c = (int)(i / N);
+  float u[3][6];
+  for (int dy = 0; dy < 3; ++dy) {
+    const float g0 = src[((size_t)(dy * 3 + 0) * C + c) * N + n], g1 = src[((size_t)(dy * 3 + 1) * C + c) * N + n],
+                g2 = src[((size_t)(dy * 3 + 2) * C + c) * N + n];
+    u[dy][0] = g0 * 0.25f;
+    u[dy][1] = -((g0 + g2) + g1) * (1.f / 6.f);
+    u[dy][2] = -((g0 + g2) - g1) * (1.f / 6.f);
+    u[dy][3] = (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) + g1 * (1.f / 12.f);
+    u[dy][4] = (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) - g1 * (1.f / 12.f);
+    u[dy][5] = g2;
+  }
+  for (int nu = 0; nu < 6; ++nu) {
+    const float U[4] = {u[0][nu], ((u[0][nu] + u[2][nu]) + u[1][nu]) * 0.5f, ((u[0][nu] + u[2][nu]) - u[1][nu]) * 0.5f, u[2][nu]};
+    for (int mu = 0; mu < 4; ++mu)
+      dst[(((((size_t)(n / 32) * (C / 8) + c / 8) * 4 + mu) * 6 + nu) * 2 + (c % 8) / 4) * 128 + (n % 32) * 4 + c % 4] = U[mu];
+  }
+}
+
 __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(a[i] - b[i]));
@@ -232,6 +260,7 @@ int main(int argc, char** argv) {
     float *d_in, *d_w, *d_wt, *d_wh, *d_ww, *d_w8, *d_b, *d_out, *d_zero, *d_ref, *d_md;
     unsigned short *d_ws, *d_wx;
     float* d_w43;
+    float* d_w2d;
     CK(hipMalloc(&d_in, n_in * 4));
     CK(hipMalloc(&d_w, n_w * 4));
     CK(hipMalloc(&d_wt, n_w * 4));
@@ -241,6 +270,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_w8, n_w * 4 * 12 / 9 + 64));
     CK(hipMalloc(&d_wx, n_w * 4 * 12 / 9 + 64));
     CK(hipMalloc(&d_w43, n_w * 4 * 18 / 9 + 64));
+    CK(hipMalloc(&d_w2d, n_w * 4 * 24 / 9 + 64));
     CK(hipMalloc(&d_ref, n_out * 4));
     CK(hipMalloc(&d_md, 4));
     CK(hipMalloc(&d_zero, 256));
@@ -254,6 +284,7 @@ int main(int argc, char** argv) {
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_ww, sh.C, sh.Cout);
     if (sh.ks == 3 && sh.C % 16 == 0) hipLaunchKernelGGL(pack_winox3_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_wx, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino43_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_w43, sh.C, sh.Cout);
+    if (sh.ks == 3 && sh.Cout % 32 == 0) hipLaunchKernelGGL(pack_wino2d_kernel, dim3((unsigned)((n_w / 9 + 255) / 256)), dim3(256), 0, st, d_w, d_w2d, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_wino8_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_w8, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_split_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_ws, sh.C, sh.Cout);
     if (sh.ks == 3) hipLaunchKernelGGL(pack_halo_kernel, dim3((unsigned)((n_w + 255) / 256)), dim3(256), 0, st, d_w, d_wh, sh.C, sh.Cout);
@@ -268,10 +299,19 @@ int main(int argc, char** argv) {
     double ref_sum = -1;
     for (const Variant& v : variants) {
       if (sh.Cout % v.bn || sh.C % v.bkc) continue;
-      if (only_variant && !strstr(v.name, only_variant)) continue;
+      if (only_variant) {   // comma-separated substrings: any match
+        bool hit = false;
+        std::string flt(only_variant);
+        for (size_t b = 0; b <= flt.size();) {
+          const size_t e = flt.find(',', b) == std::string::npos ? flt.size() : flt.find(',', b);
+          if (e > b && strstr(v.name, flt.substr(b, e - b).c_str())) hit = true;
+          b = e + 1;
+        }
+        if (!hit) continue;
+      }
       CK(hipMemsetAsync(d_out, 0, n_out * 4, st));
       if (v.wkind >= 2 && sh.ks != 3) continue;
-      p.w = v.wkind == 7 ? d_w43 : v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
+      p.w = v.wkind == 8 ? d_w2d : v.wkind == 7 ? d_w43 : v.wkind == 6 ? reinterpret_cast<const float*>(d_wx) : v.wkind == 5 ? d_w8 : v.wkind == 3 ? reinterpret_cast<const float*>(d_ws) : v.wkind == 2 ? d_wh : v.wkind == 1 ? d_wt : d_w;
       CK(v.fn(p, st));  // warm + correctness
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
       hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
@@ -303,7 +343,7 @@ int main(int argc, char** argv) {
              flops / best * 1e-9, rel < 1e-5 ? "ok" : "(ablation)", rel, maxdiff);
       fflush(stdout);
     }
-    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ww)); CK(hipFree(d_w8)); CK(hipFree(d_w43)); CK(hipFree(d_wx)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
+    CK(hipFree(d_in)); CK(hipFree(d_w)); CK(hipFree(d_wt)); CK(hipFree(d_zero)); CK(hipFree(d_wh)); CK(hipFree(d_ww)); CK(hipFree(d_w8)); CK(hipFree(d_w43)); CK(hipFree(d_w2d)); CK(hipFree(d_wx)); CK(hipFree(d_ws)); CK(hipFree(d_ref)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   return 0;
 }
