@@ -251,6 +251,9 @@ def main():
                          'estimator (default); 2: coarse decoder levels on the side stream beside the estimator (measured slower)')
     ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
                     help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
+    ap.add_argument('--flow-scale', type=float, default=1.0,
+                    help='experiment: multiply the last 1x1 layer of every flow predictor (kernel and bias) by this (0 = zero flows: every warp '
+                         'is the identity, the smoothest possible gather; 1 = the seeded synthetic weights)')
     ap.add_argument('--wino2d', type=int, default=None, choices=[0, 1, 2], help='engine option "wino2d" (nested Winograd kernel); default: the engine default')
     ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
     ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
@@ -299,6 +302,10 @@ def main():
     weights = None
     if rank == 0:
         weights = W.make_synthetic_weights(PUBLISHED, seed=0)
+        if args.flow_scale != 1.0:
+            for k in list(weights):
+                if k.startswith('predict_flow') and '/conv_4/' in k:
+                    weights[k] = (weights[k] * np.float32(args.flow_scale)).astype(np.float32)
         eng.set_weights(weights)
     if world > 1:
         # one-time RCCL broadcast of the packed weight blob (137.7 MB) from rank 0

@@ -13,7 +13,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-ENGINE = re.compile(r'conv_buf_kernel|conv_halo_kernel|conv_wino43_kernel|conv_wino_kernel|conv_winox3_kernel|conv_foldx3_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_c3_kernel|conv_splitk_reduce_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
+ENGINE = re.compile(r'conv_buf_kernel|conv_halo_kernel|conv_wino43_kernel|conv_wino2d_kernel|conv_wino_kernel|conv_winox3_kernel|conv_foldx3_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_c3_kernel|conv_splitk_reduce_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
                     r'pool_vec_kernel|pool_c3_kernel|flow_up_kernel|flow_add_kernel|pack_flow_kernel|frame_to_tiles_kernel|'
                     r'tiles_to_frame_kernel')
 
