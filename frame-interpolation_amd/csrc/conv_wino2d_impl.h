@@ -80,7 +80,10 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   if (stager && a_y >= 0 && a_y < p.H)
     for (int j = 0; j < 6; ++j)
       if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
-  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ (QW >= 16 ? ((tq >> 3) & 1) : (ahy & 1))) << 2);
+  // K-half swap so that a 16-lane fragment read covers all 64 banks once: QW >= 16 on bit 3 of the quad; QW = 8 (16 lanes = two
+  // unit rows, i.e. halo rows TWO apart) on bit 1 of the halo row (bit 0 would give both rows the same half: measured as 35 %
+  // of the LDS cycles in bank conflicts, profiles/r03_pmc_conv_bench_w2d.md)
+  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ (QW >= 16 ? ((tq >> 3) & 1) : ((ahy >> 1) & 1))) << 2);
   const int scol = aq * 4;
   unsigned a_off = 0, a_pix = 0;
   unsigned aoffj[6];   // byte offsets of the item's six pixels (out of range where the pixel is outside the image): fixed per
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int ra = mu == 0 ? 0 : mu == 2 ? 2 : 1, rb = mu == 0 ? 2 : mu == 1 ? 2 : mu == 2 ? 1 : 3;
   const float sgn = mu == 1 ? 1.f : -1.f;
   auto row_ad = [&](int hy) {   // float4 index of (halo row hy, nu 0, quad lq, this lane's K half)
-    const int sw = QW >= 16 ? ((lq >> 3) & 1) : (hy & 1);
+    const int sw = QW >= 16 ? ((lq >> 3) & 1) : ((hy >> 1) & 1);
     return ((hy * 6) * QW + lq) * 2 + (half ^ sw);
   };
   const int ad_a = row_ad(2 * ur + ra), ad_b = row_ad(2 * ur + rb);
