@@ -411,7 +411,7 @@ def main():
         # FLOPs the matrix pipe really executes: the Winograd F(2,3) kernel (tile id & 256) does 2/3 of the direct
         # convolution's multiplies, the sub-pixel-folded upsample + 2x2 conv (tag ':phases') 9/16
         exec_flops = 0.0
-        dom = {'launches': 0, 'ms': 0.0, 'executed_flops': 0.0}     # the dominant kernel alone: conv_wino43_kernel
+        per_kernel = {k: {'launches': 0, 'ms': 0.0, 'executed_flops': 0.0} for k in ('conv_wino2d_kernel', 'conv_wino43_kernel')}
         for o in prof['ops']:
             if o['kind'] != 'conv_mfma':
                 continue
@@ -423,10 +423,11 @@ def main():
             elif o['tag'].endswith(':phases'):
                 f *= 9.0 / 16.0
             exec_flops += f
-            if (o['tile'] & 256) and (o['tile'] & 2048) and not (o['tile'] & 8192):
-                dom['launches'] += 1
-                dom['ms'] += o['ms']
-                dom['executed_flops'] += f
+            kname = 'conv_wino2d_kernel' if (o['tile'] & 8192) else 'conv_wino43_kernel' if ((o['tile'] & 256) and (o['tile'] & 2048)) else None
+            if kname:
+                per_kernel[kname]['launches'] += 1
+                per_kernel[kname]['ms'] += o['ms']
+                per_kernel[kname]['executed_flops'] += f
         exec_tflops = exec_flops / (conv['ms'] * 1e-3) / 1e12
         traffic, traffic_src = None, None
         try:  # fabric-side bytes per conv launch REPLAYED from the committed PMC passes of an earlier run (profiles/)
@@ -450,13 +451,21 @@ def main():
                        '(v_mfma_f32_32x32x16_bf16, fp32 accumulate) + the fp32 kernels on the small / 2x2 layers; '
                        'peak = dense bf16 MFMA peak / bf16 products per fp32 product'),
             'achieved': round(exec_tflops, 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-            'frac': round(exec_tflops / peak, 4), 'traffic': traffic if not args.precision else None,
+            'frac': round(exec_tflops / peak, 4),
+            'frac_note': 'utilisation of the peak by the multiplies the matrix pipe EXECUTES; the kernels that execute fewer of them per output '
+                         '(conv_wino2d_kernel: 1/3 of the direct count) lower it while the step gets faster - see direct_equivalent and kernels[]',
+            'traffic': traffic if not args.precision else None,
             'traffic_note': (f'REPLAYED, not measured in this run: bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the rocprofv3 PMC passes '
                              f'committed in {traffic_src} (an earlier run of this kernel set; PMC needs its own rocprofv3 process)') if traffic else None,
-            'dominant_kernel': {'name': 'conv_wino43_kernel', 'launches': dom['launches'], 'ms': round(dom['ms'], 3),
-                                'executed_tflops': round(dom['executed_flops'] / max(dom['ms'], 1e-9) / 1e9, 3),
-                                'frac': round(dom['executed_flops'] / max(dom['ms'], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
-                                'avg_launch_ms': round(dom['ms'] / max(1, dom['launches']), 5)} if not args.precision else None,
+            # the two Winograd kernels on their own (executed FLOPs: nested F(4,3)x x F(2,3)y = 1/3, 1-D F(4,3) = 1/2 of the direct
+            # count); `dominant_kernel` = the one with the larger share of the step
+            'kernels': None if args.precision else [
+                {'name': k, 'launches': v['launches'], 'ms': round(v['ms'], 3),
+                 'executed_tflops': round(v['executed_flops'] / max(v['ms'], 1e-9) / 1e9, 3),
+                 'frac': round(v['executed_flops'] / max(v['ms'], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                 'direct_equivalent_tflops': round(v['executed_flops'] * (3.0 if k == 'conv_wino2d_kernel' else 2.0) / max(v['ms'], 1e-9) / 1e9, 3),
+                 'avg_launch_ms': round(v['ms'] / max(1, v['launches']), 5)}
+                for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms']) if v['launches']],
             'launches_per_step': conv['launches'],
             'avg_launch_ms': round(conv['ms'] / conv['launches'], 5),
             'class_ms_per_step': round(conv['ms'], 3),
@@ -468,6 +477,7 @@ def main():
                                   'note': 'same launches priced with the direct convolution\'s FLOPs (SURVEY 8d formula); exceeds the fp32 MFMA '
                                           'peak because Winograd / the sub-pixel fold execute fewer multiplies - an algorithmic saving, not a utilisation'},
         }
+        roofline['dominant_kernel'] = roofline['kernels'][0] if roofline.get('kernels') else None
         extra = {}
         if 'warp' in cls:
             wgbs = cls['warp']['bytes'] / (cls['warp']['ms'] * 1e-3) / 1e9
