@@ -10,6 +10,23 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 
+def _keep_large_allocations_in_the_heap():
+    """The oracle's numpy temporaries are 100s of MB each; glibc serves such requests with mmap / munmap, i.e. fresh zeroed
+    pages and their page faults on every one (on this VM, which hands freed memory back to its host: 3 minutes of system
+    time in ONE 1024x768 oracle forward).  Without mmap-served requests and without heap trimming the freed pages are reused."""
+    try:
+        import ctypes
+        libc = ctypes.CDLL('libc.so.6')
+        M_TRIM_THRESHOLD, M_MMAP_MAX = -1, -4
+        libc.mallopt(M_MMAP_MAX, 0)                       # no mmap-served requests at all: everything comes from the heap ...
+        libc.mallopt(M_TRIM_THRESHOLD, (1 << 31) - 1)     # ... and freed heap pages are kept (and reused) instead of returned
+    except Exception:   # pragma: no cover - a speed-up only
+        pass
+
+
+_keep_large_allocations_in_the_heap()
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
 
