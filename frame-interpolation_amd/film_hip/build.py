@@ -12,8 +12,8 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
 OUT = os.path.join(_HERE, 'libfilm_hip.so')
-SOURCES = ['conv_igemm.hip', 'misc_kernels.hip', 'film_engine.cpp']
-HEADERS = ['film_kernels.h', 'conv_igemm_impl.h', 'conv_buf_impl.h', 'conv_halo_impl.h', 'conv_split_impl.h', 'conv_wino_impl.h', 'conv_wino43_impl.h', 'conv_wino2d_impl.h', 'conv_winox3_impl.h', 'conv_foldx3_impl.h', 'conv_c3_impl.h', os.path.join('..', '..', 'include', 'film_hip.h')]
+SOURCES = ['conv_igemm.hip', 'misc_kernels.hip', 'film_engine.cpp', 'film_planner.cpp', 'film_layers.cpp']
+HEADERS = ['film_kernels.h', 'film_internal.h', 'conv_igemm_impl.h', 'conv_buf_impl.h', 'conv_halo_impl.h', 'conv_split_impl.h', 'conv_wino_impl.h', 'conv_wino43_impl.h', 'conv_wino2d_impl.h', 'conv_winox3_impl.h', 'conv_foldx3_impl.h', 'conv_c3_impl.h', os.path.join('..', '..', 'include', 'film_hip.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 
 
@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError('hipcc failed: ' + ' '.join(cmd))
-    if force or procs or _stale(OUT, objs):
+    if force or procs or _stale(OUT, objs + [os.path.join(CSRC, 'film_hip.map')]):
         # ONE HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so (no SONAME,
         # its libraries NEED the unversioned name "libamdhip64.so"); linking against
         # /opt/rocm/lib/libamdhip64.so would record the SONAME "libamdhip64.so.7", which glibc does not
@@ -59,6 +59,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         subprocess.check_call(['gcc', '-shared', '-fPIC', '-o', os.path.join(stub_dir, 'libamdhip64.so'), stub_c])
         rocm_lib = os.path.join(os.environ.get('ROCM_PATH', '/opt/rocm'), 'lib')
         cmd = ['g++', '-shared', '-fPIC', '-o', OUT] + objs + [
+            '-Wl,--version-script,' + os.path.join(CSRC, 'film_hip.map'),      # exports = the C-ABI of include/film_hip.h, nothing else
             '-L' + stub_dir, '-Wl,--no-as-needed', '-lamdhip64', '-Wl,--as-needed',
             '-Wl,-rpath,' + rocm_lib, '-Wl,--enable-new-dtags']
         if verbose:
