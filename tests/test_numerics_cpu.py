@@ -4,7 +4,7 @@
   operation order of the kernels / the weight packer, against the direct 3-tap correlation in float64;
 * the round-to-nearest-even bf16 split of conv_split_impl.h: hi + mid + lo == x exactly, |x - hi - mid| <= 2^-17 |x|,
   and the bf16x3 product hi*hi + hi*mid + mid*hi within 2^-15 of the exact product (4.4e-6 rms) with (near) zero mean error;
-* the sub-pixel fold of nearest-x2 upsample + 2x2 'same' convolution (film_engine.cpp / conv_foldx3_impl.h).
+* the sub-pixel fold of nearest-x2 upsample + 2x2 'same' convolution (film_planner.cpp / film_layers.cpp / conv_foldx3_impl.h).
 """
 import numpy as np
 
@@ -12,7 +12,7 @@ f32 = np.float32
 
 
 def bf16_rne(x):
-    """float32 -> bfloat16 (returned as float32), round to nearest even: film_engine.cpp bf16_rne / v_cvt_pk_bf16_f32."""
+    """float32 -> bfloat16 (returned as float32), round to nearest even: film_layers.cpp bf16_rne / v_cvt_pk_bf16_f32."""
     u = np.asarray(x, f32).view(np.uint32).astype(np.uint64)
     u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
     return u.astype(np.uint32).view(f32)
@@ -73,7 +73,7 @@ def test_winograd_f23_and_f43_transforms():
     for _ in range(2000):
         g = (rng.standard_normal(3) * 0.1).astype(f32)
         d = rng.standard_normal(6).astype(f32)
-        # F(2,3): weights as packed in film_engine.cpp, inputs as in conv_wino_impl.h store_item
+        # F(2,3): weights as packed in film_layers.cpp, inputs as in conv_wino_impl.h store_item
         g0, g1, g2 = g
         u = [g0, ((g0 + g2) + g1) * f32(0.5), ((g0 + g2) - g1) * f32(0.5), g2]
         for t in (0, 2):                                   # two pairs out of the six inputs
@@ -82,7 +82,7 @@ def test_winograd_f23_and_f43_transforms():
             m = [f32(u[i]) * f32(v[i]) for i in range(4)]
             y = np.array([(m[0] + m[1]) + m[2], (m[1] - m[2]) - m[3]], f32)
             err23.append(np.abs(y - _direct3(d[t:t + 4], g)).max())
-        # F(4,3): weights as packed in film_engine.cpp, inputs as in conv_wino43_impl.h store_item (fused multiply-adds)
+        # F(4,3): weights as packed in film_layers.cpp, inputs as in conv_wino43_impl.h store_item (fused multiply-adds)
         c6, c12, c24 = f32(1) / f32(6), f32(1) / f32(12), f32(1) / f32(24)
         e, o = g0 * c24 + g2 * c6, g1 * c12
         u = [g0 * f32(0.25), -((g0 + g2) + g1) * c6, -((g0 + g2) - g1) * c6, e + o, e - o, g2]
