@@ -362,7 +362,12 @@ struct Planner {
       if (l == L - 1) {
         sb.v = view(feat[l], 0, 0, fc[l]); sb.boff = B; sb.bmod = N2;  // the other image's features
       } else {
-        if (!(h->opt_fuse & 1)) {
+        // tf.image.resize(2 * v) inside the warps that consume it (fuse bit 1) pays on the small, launch-bound levels; on the
+        // large ones every (pixel, channel group) thread of the warp would recompute the flow behind four gathers, a second
+        // memory round trip in front of the corner loads: there the separate (2-channel) resize launch is faster - 1080p step
+        // 45.8 -> 45.5 ms, warp class 3.18 -> 2.90 + 0.06 ms (profiles/r03_fuse_ab.log).  Same arithmetic either way.
+        const bool fuse_up = (h->opt_fuse & 1) && (int64_t)Hl * Wl < 100000;
+        if (!fuse_up) {
           OpDesc up;
           up.kind = OP_FLOW_UP; up.tag = tg + ":resize2x";
           up.in = view(v[l + 1], 0, 0, 2); up.out = view(vup[l], 0, 0, 2);
@@ -373,7 +378,7 @@ struct Planner {
         for (int d = 0; d < 2; ++d) {  // warp the OTHER image's features with this direction's flow
           warp(tg + ":warp_d" + std::to_string(d), view(feat[l], (1 - d) * B, 0, fc[l]), view(vup[l], d * B, 0, 2),
                view(warped[l], d * B, 0, fc[l]), B, Hl, Wl, 1.f);
-          if (h->opt_fuse & 1) {
+          if (fuse_up) {
             // tf.image.resize(2 * v) (pyramid_flow_estimator.py:155) inside the warp: the flow of this level is computed
             // from the coarser level's v by every thread of a pixel and stored once (to vup, which v = res + up reads)
             OpDesc& w = P->ops.back();

@@ -385,3 +385,27 @@ def test_default_plan_uses_the_nested_kernel_on_the_deep_layers_of_a_1080p_tile(
     d = float(np.abs(a - b0).max())
     print(f'960x576 tile, default plan with vs without conv_wino2d_kernel: max|d| {d:.2e}')
     assert d < 5e-5
+
+
+def test_graph_replay_on_changing_inputs_at_a_1080p_tile(published):
+    """The two-lane hipGraph replay vs eager launches on the headline tile (960x576: the only size where the flow upsample is
+    its own launch on the two large levels and fused into the warps below them, and where conv_wino2d_kernel is in the default
+    plan), with inputs that change every forward - a stale read in the replayed graph would show as the previous forward's
+    data: image and every aligned level bit-identical; also with the decoder-on-the-side-lane op order ("lanes" = 2)."""
+    from film_hip.engine import FilmEngine
+    opt, w, eg = published
+    ee = FilmEngine(opt, device=0)
+    ee.set_weights(w)
+    ee.set_option('graph', 0)
+    kinds = [o['kind'] for o in eg.plan(1, 576, 960)['ops']]
+    assert kinds.count('flow_up') == 2 and any('+resize2x' in o['tag'] for o in eg.plan(1, 576, 960)['ops'])
+    for lanes in (1, 2):
+        eg.set_option('lanes', lanes)
+        for it in range(3):
+            x0, x1 = TI.frame_pair(1, 576, 960, seed=70 + it)
+            a, c = eg.forward(x0, x1), ee.forward(x0, x1)
+            assert np.array_equal(a, c), (lanes, it, float(np.abs(a - c).max()))
+            for l in range(opt.fusion_pyramid_levels):
+                assert np.array_equal(eg.tap(f'aligned{l}'), ee.tap(f'aligned{l}')), (lanes, it, l)
+    eg.set_option('lanes', 1)
+    ee.close()
