@@ -24,7 +24,20 @@
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
+enum { W2D_F_PFA = 128,       // touch-ahead for the activations: per chunk every staging thread reads ONE dword of the next 128-B line of
+                              // one of its pixels, issued after the chunk's real loads (in-order vmcnt: it has two chunk times to
+                              // land) - the item loads three to six chunks later then hit L2 instead of waiting for HBM
+       W2D_F_PFB = 8192,      // the same for the weight slab of chunk kc + 3 (48 lines of 128 B: one dword load on 48 lanes)
+       W2D_DBG_AHOT = 4096,   // timing ablation: every activation load from the first 64 KB of the tensor (same requests, all cache hits)
+       W2D_DBG_NOAST = 32768, // timing ablation: item loads issued, no transform / LDS store
+       W2D_DBG_NOALD = 65536, // timing ablation: transform + LDS store of whatever the registers hold, no item loads
+       W2D_F_RAW = 131072,    // the halo patch goes to LDS RAW first: buffer_load_dwordx4 ... lds, 16 channels (one 64-B sector per pixel) per
+                              // request, 16 pixels per instruction, every wave issuing its share; the staging threads then read their
+                              // six pixels from LDS instead of gathering 16 B per lane from memory (3.5x fewer, fully used sectors
+                              // requested; no activation registers in flight).  Needs every input segment's C % 16 == 0
+       W2D_F_LATE = 16384,    // with W2D_F_ILV: the transform sits on nu steps 2..5 instead of 0..3 - the item loads (the LAST requests of the
+                              // previous chunk) get another half chunk before the wave waits for them
+       W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
                               // gaps between MFMA groups) instead of sitting between the last MFMA and the barrier
        W2D_DBG_NOB = 256,     // timing ablations (tools/conv_bench.hip only; results are wrong on purpose): no weight loads in the K loop
        W2D_DBG_NOCOMB = 512,  // no second fragment read / no y combine
@@ -44,6 +57,14 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   constexpr int PXW = 4 * QW;
   static_assert(ITEMS <= NT, "staging items");
   constexpr unsigned OOB = 0xFFFFFFFFu;
+  constexpr bool RAW = (FLAGS & W2D_F_RAW) != 0;
+  constexpr int PW = PXW + 2;                  // halo pixels per patch row
+  constexpr int NPIX = HR * PW;
+  constexpr int NI = (NPIX + 15) / 16;         // raw requests (16 pixels x 64 B = 1 KB of LDS each) per 16-channel super-chunk
+  constexpr int IPW = (NI + NW - 1) / NW;      // per wave
+  constexpr int R_STAGE = IPW * NW * 256;      // floats of one raw buffer (every wave issues IPW requests; those past NI write
+                                               // zeros behind the patch); LDS: [A0][A1][R0][R1]
+  static_assert(!RAW || QW == 8, "raw staging: 8-quad patch rows");
 
   extern __shared__ __attribute__((aligned(1024))) float smem[];  // [A0][A1]; the epilogue reuses it as the exchange buffer
 
@@ -86,6 +107,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ (QW >= 16 ? ((tq >> 3) & 1) : ((ahy >> 1) & 1))) << 2);
   const int scol = aq * 4;
   unsigned a_off = 0, a_pix = 0;
+  unsigned pfo[2] = {OOB, OOB};   // W2D_F_PFA: the pixel this thread touches ahead on even / odd chunks (pixels 1..4 of the quad between
+                                  // the two channel-group threads and the two chunk parities: every pixel of the row once per two chunks)
   unsigned aoffj[6];   // byte offsets of the item's six pixels (out of range where the pixel is outside the image): fixed per
                        // segment, so that a chunk's loads need no address arithmetic and the registers stay theirs
   conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
@@ -101,8 +124,15 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       aoffj[j] = ((a_ok >> j) & 1u) ? a_off + (unsigned)j * a_pix : OOB;
+      if constexpr ((FLAGS & W2D_DBG_AHOT) != 0) aoffj[j] = ((a_ok >> j) & 1u) ? (aoffj[j] & 0xFFF0u) + (unsigned)(p.W * s.stride) * 4u : OOB;
       asm volatile("" : "+v"(aoffj[j]));   // keep it in its register (hipcc otherwise recomputes it per chunk into registers that
                                            // are still the destination of loads in flight, and has to wait for those)
+    }
+    if constexpr ((FLAGS & W2D_F_PFA) != 0) {
+      pfo[0] = aq ? aoffj[3] : aoffj[1];
+      pfo[1] = aq ? aoffj[4] : aoffj[2];
+      asm volatile("" : "+v"(pfo[0]));
+      asm volatile("" : "+v"(pfo[1]));
     }
   };
   const int nkc = p.Ctot / 8;
@@ -110,7 +140,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   bool chunk_ok = true;
   auto load_item = [&](auto set_c) {
     constexpr int SET = decltype(set_c)::value;
-    const unsigned so = (unsigned)c0 * 4u;
+    const unsigned so = (FLAGS & W2D_DBG_AHOT) ? ((unsigned)c0 * 4u) & 96u : (unsigned)c0 * 4u;
 #pragma unroll
     for (int j = 0; j < 6; ++j) araw[SET][j] = conv_buf_load(arsrc, aoffj[j], so);
   };
@@ -138,10 +168,80 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       chunk_ok = false;
 #pragma unroll
       for (int j = 0; j < 6; ++j) aoffj[j] = OOB;
+      pfo[0] = pfo[1] = OOB;
       return;
     }
     c0 += 8;
     if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
+  };
+
+  // ---- W2D_F_RAW: raw halo patch in LDS.  Request i of a super-chunk covers linear halo pixels P = 16 i .. 16 i + 15 (P = halo
+  // row * PW + pixel), lane l -> LDS slot l of the request's 1 KB (that is how `buffer_load ... lds` places the lanes).  The
+  // slot <-> (pixel q = P & 15, 16-B piece c = 2 h + a) map is chosen for the READ side: the 16 lanes of a ds_read_b128
+  // group are the items (a, quad 0..7) of one halo row = pixels FOUR apart, same h; slot = (q & 3) * 16 + (h ^ (i & 1)) * 8 +
+  // (q >> 2) * 2 + a gives them 16 different slots mod 16 (all 64 banks once).
+  unsigned rvoff[IPW];
+  int rsg = 0, rc0 = 0, rsegC = 0;
+  conv_rsrc_t rrsrc = conv_make_rsrc(p.seg[0].ptr);
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  unsigned rbad = 0;   // bit n: request n of this lane is outside the image (or past the patch)
+  auto raw_pixel = [&](int n, int& pc) {   // this lane's (pixel of the patch row block, piece) of its wave's n-th request
+    const int i = wv + NW * n;
+    const int q = ((lane >> 1) & 3) * 4 + (lane >> 4), h = ((lane >> 3) & 1) ^ (i & 1);
+    pc = 2 * h + (lane & 1);
+    return 16 * i + q;
+  };
+  if constexpr (RAW) {
+#pragma unroll
+    for (int n = 0; n < IPW; ++n) {
+      int pc;
+      const int P = raw_pixel(n, pc), hy = P / PW, px = P - hy * PW;
+      const int y = y0 - 1 + hy, x = x0 - 1 + px;
+      if (!(P < NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W)) rbad |= 1u << n;
+    }
+  }
+  auto raw_setup_seg = [&]() {
+    const ConvSeg& s = p.seg[rsg];
+    rsegC = s.C;
+    int be = img + s.boff;
+    if (s.bmod && be >= s.bmod) be -= s.bmod;
+    rrsrc = conv_make_rsrc(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride);
+#pragma unroll
+    for (int n = 0; n < IPW; ++n) {
+      int pc;
+      const int P = raw_pixel(n, pc), hy = P / PW, px = P - hy * PW;
+      rvoff[n] = ((unsigned)((hy * p.W + (x0 - 1 + px)) * s.stride + pc * 4) * 4u) | (0u - ((rbad >> n) & 1u));
+      asm volatile("" : "+v"(rvoff[n]));
+    }
+  };
+  auto raw_issue = [&](int buf) {   // the next super-chunk (16 channels) of the patch -> raw buffer `buf`; advances the raw cursor
+    const unsigned so = (unsigned)rc0 * 4u;
+    const unsigned base = lds0 + (unsigned)(2 * A_STAGE + buf * R_STAGE) * 4u + (unsigned)wv * 1024u;
+#pragma unroll
+    for (int n = 0; n < IPW; ++n)
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(base + (unsigned)(NW * n) * 1024u), "v"(rvoff[n]), "s"(rrsrc), "s"(so)
+                   : "memory");   // (m0 is reserved in the AMDGPU backend: the compiler writes it right at each of its own uses and
+                                  // never keeps a value there across other code, so it is not - and cannot be - listed as a clobber)
+    rc0 += 16;
+    if (rc0 >= rsegC && rsg + 1 < p.nseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
+  };
+  // read side: float4 index (within a raw buffer) of pixel j of this thread's item, piece a = aq, for h = 0 (h = 1: ^ 8)
+  unsigned xj[6];
+  if constexpr (RAW) {
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int P = ahy * PW + 4 * tq + j, i = P >> 4, q = P & 15;
+      xj[j] = (unsigned)(i * 64 + (((q & 3) * 16 + (q >> 2) * 2 + aq) | ((i & 1) << 3)));
+    }
+  }
+  const bf4* const smem4r = reinterpret_cast<const bf4*>(smem);
+  auto raw_read = [&](bf4 (&rv)[6], int buf, int h) {
+    const unsigned b4 = (unsigned)(2 * A_STAGE + buf * R_STAGE) / 4u, hx = (unsigned)h << 3;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      asm volatile("" : "+v"(xj[j]));   // opaque: otherwise the four (buffer, h) address sets are hoisted out of the K loop (24 registers)
+      rv[j] = smem4r[b4 + (xj[j] ^ hx)];
+    }
   };
 
   // ---- weights: [Cout / 32][chunk][mu][nu][K half][32][4] floats; this wave reads slab (ct, kc, mu): 6 x 1 KB -----------------
@@ -149,6 +249,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const int ct = n0 / 32 + ng;
   bf4 fbg[2][6];
+  float pfa[2] = {0.f, 0.f}, pfb[2] = {0.f, 0.f};   // touch-ahead destinations (never read; kept live until the load has landed)
+  const unsigned pfb_off = lane < 48 ? (unsigned)lane * 128u : OOB;
   auto load_b = [&](int kc, auto set_c) {
     constexpr int SET = decltype(set_c)::value;
     const unsigned so = (unsigned)(((ct * nkc + (kc < nkc ? kc : nkc - 1)) * 4 + mu) * 6) * 1024u;
@@ -181,26 +283,56 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // return zero without touching memory - so that all waves have the SAME number of loads in flight: with the loads under
   // `if (stager)` the compiler has to place one s_waitcnt vmcnt(n) valid for both paths, and the staging waves then wait
   // for the weight loads they issued a moment ago (a full L2 latency per chunk)
-  setup_seg();
-  load_item(C0{});
-  load_b(0, C0{});
-  // (the chunk / segment state - c0, the buffer resource - advances on EVERY thread: kept uniform it lives in scalar
-  // registers; advanced under `if (stager)` it becomes a per-lane value and every buffer load turns into a waterfall loop)
-  next_chunk(1);
-  load_item(C1{});
-  if (stager) store_item(0, C0{});
-  next_chunk(2);
-  __syncthreads();
+  const int nsc = nkc / 2;   // W2D_F_RAW: super-chunks
+  if constexpr (RAW) {
+    raw_setup_seg();
+    raw_issue(0);
+    if (nsc > 1) raw_issue(1);
+    load_b(0, C0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (stager) {
+      raw_read(araw[0], 0, 0);
+      store_item(0, C0{});
+    }
+    __syncthreads();
+  } else {
+    setup_seg();
+    load_item(C0{});
+    load_b(0, C0{});
+    // (the chunk / segment state - c0, the buffer resource - advances on EVERY thread: kept uniform it lives in scalar
+    // registers; advanced under `if (stager)` it becomes a per-lane value and every buffer load turns into a waterfall loop)
+    next_chunk(1);
+    load_item(C1{});
+    if (stager) store_item(0, C0{});
+    next_chunk(2);
+    __syncthreads();
+  }
 
   auto chunk = [&](int kc, auto par_c) {
     constexpr int PAR = decltype(par_c)::value;
     const int sa = (kc & 1) * A_STAGE4;
+    if constexpr (RAW && PAR == 1 && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOALD)) == 0) {   // odd chunk: raw buffer (kc >> 1) & 1 was last read in chunk kc - 1; refill it with super-chunk
+                                       // (kc >> 1) + 2.  Issued BEFORE the weight requests: the compiler's vmcnt counts for those stay
+                                       // exact, and the wait for the last weight slab of chunk kc + 1 covers these (in-order return),
+                                       // so the barrier that ends chunk kc + 1 publishes the buffer - first read in chunk kc + 2
+      if ((kc >> 1) + 2 < nsc) raw_issue((kc >> 1) & 1);
+    }
     if constexpr ((FLAGS & W2D_DBG_NOB) == 0) load_b(kc + 1, std::integral_constant<int, 1 - PAR>{});
-    if constexpr ((FLAGS & W2D_DBG_NOA) == 0) load_item(par_c);   // chunk kc + 2 into the register set chunk kc came from
+    if constexpr (!RAW && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOALD)) == 0) load_item(par_c);   // chunk kc + 2 into the register set chunk kc came from
+    if constexpr ((FLAGS & W2D_F_PFA) != 0) {   // after the real loads: in-order completion then gives the touch two chunk times
+      asm volatile("" ::"v"(pfa[PAR]));
+      pfa[PAR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (int)pfo[PAR], (int)((unsigned)c0 * 4u + 128u), 0));
+    }
+    if constexpr ((FLAGS & W2D_F_PFB) != 0) {
+      asm volatile("" ::"v"(pfb[PAR]));
+      const unsigned so3 = (unsigned)(((ct * nkc + (kc + 3 < nkc ? kc + 3 : nkc - 1)) * 4 + mu) * 6) * 1024u;
+      pfb[PAR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)pfb_off, (int)so3, 0));
+    }
     __builtin_amdgcn_sched_barrier(0);   // the twelve requests of the chunk go out first, in this order (the s_waitcnt counts below rely on it)
     bf4 fa[2], fb2[2];
     bf4 sv[6];   // W2D_F_ILV: the item of chunk kc + 1, transformed two channels per nu step
-    constexpr bool ILV = (FLAGS & W2D_F_ILV) != 0 && (FLAGS & W2D_DBG_NOA) == 0;
+    constexpr bool ILV = (FLAGS & W2D_F_ILV) != 0 && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0;
     auto xform = [&](int c) {
       constexpr int SET = 1 - PAR;
       const float d0 = araw[SET][0][c], d1 = araw[SET][1][c], d2 = araw[SET][2][c], d3 = araw[SET][3][c], d4 = araw[SET][4][c], d5 = araw[SET][5][c];
@@ -228,15 +360,27 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       for (int k = 0; k < 4; ++k) a[k] = COMB ? __builtin_fmaf(sgn, fb2[j & 1][k], fa[j & 1][k]) : fa[j & 1][k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], fbg[PAR][j][k], acc[j], 0, 0, 0);
+      if constexpr ((FLAGS & W2D_DBG_NOAST) != 0) {
+        if (j == ((FLAGS & W2D_F_LATE) ? 2 : 0)) {
+#pragma unroll
+          for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(araw[1 - PAR][q][c]));
+        }
+      }
+      if constexpr (RAW && ILV) {
+        if (j == 0 && stager) raw_read(araw[1 - PAR], ((kc + 1) >> 1) & 1, 1 - PAR);   // the item of chunk kc + 1: h = (kc + 1) & 1
+      }
       if constexpr (ILV) {
         if (stager) {
-          if (j == 0) { xform(0); xform(1); }
-          if (j == 1) { xform(2); xform(3); }
-          if (j == 2) {
+          constexpr int J0 = (FLAGS & W2D_F_LATE) ? 2 : 0;
+          if (j == J0) { xform(0); xform(1); }
+          if (j == J0 + 1) { xform(2); xform(3); }
+          if (j == J0 + 2) {
 #pragma unroll
             for (int nu = 0; nu < 3; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
           }
-          if (j == 3) {
+          if (j == J0 + 3) {
 #pragma unroll
             for (int nu = 3; nu < 6; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
           }
@@ -244,9 +388,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!ILV && (FLAGS & W2D_DBG_NOA) == 0) { if (stager) store_item((kc + 1) & 1, std::integral_constant<int, 1 - PAR>{}); }   // chunk kc + 1
+    if constexpr (!ILV && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0) { if (stager) store_item((kc + 1) & 1, std::integral_constant<int, 1 - PAR>{}); }   // chunk kc + 1
     if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
-    next_chunk(kc + 3);
+    if constexpr (!RAW) next_chunk(kc + 3);
   };
   for (int kc = 0; kc < nkc; kc += 2) {
     chunk(kc, C0{});
@@ -296,13 +440,30 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 
 template <int TH, int BN, int FLAGS, int QW = 8>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
-  constexpr size_t a_bytes = 2 * (size_t)(TH + 2) * 6 * QW * 8 * sizeof(float);
+  constexpr int NWL = 4 * (BN / 32), NIL = ((TH + 2) * (4 * QW + 2) + 15) / 16;
+  constexpr size_t r_bytes = (FLAGS & W2D_F_RAW) ? 2 * (size_t)(((NIL + NWL - 1) / NWL) * NWL) * 1024 : 0;
+  constexpr size_t a_bytes = 2 * (size_t)(TH + 2) * 6 * QW * 8 * sizeof(float) + r_bytes;
   constexpr size_t x_bytes = (size_t)(BN / 32) * 2 * 16 * 64 * sizeof(float);
   constexpr size_t lds = a_bytes > x_bytes ? a_bytes : x_bytes;
   constexpr int NT = 4 * (BN / 32) * 64;
-  static_assert(lds <= 64 * 1024, "LDS");
+  static_assert(lds <= 80 * 1024, "LDS (two workgroups per CU with BN = 32)");
+  if constexpr ((FLAGS & W2D_F_RAW) != 0) {
+    if (p.Ctot % 16) return hipErrorInvalidValue;
+    for (int i = 0; i < p.nseg; ++i)
+      if (p.seg[i].C % 16 || p.seg[i].stride % 16 || p.seg[i].up) return hipErrorInvalidValue;
+  }
   if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 8 || p.Cout % BN) return hipErrorInvalidValue;
   auto kern = conv_wino2d_kernel<TH, BN, FLAGS, QW>;
+  if constexpr (lds > 64 * 1024) {
+    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
+    }
+  }
   const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);

@@ -165,8 +165,18 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
   return out;
 }
 
-std::vector<int> wino2d_candidates(int Cout) {
+static bool wino2d_raw_ok(const OpDesc& op) {
+  for (int i = 0; i < op.nseg; ++i)
+    if (op.seg[i].v.C % 16 || op.seg[i].v.stride % 16 || op.seg[i].v.off % 4 || op.seg[i].up) return false;
+  return op.Ctot % 16 == 0;
+}
+
+std::vector<int> wino2d_candidates(int Cout, bool raw_ok) {
   std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W2D_Q8_8x64, W2D_Q8_8x32, W2D_Q16_4x64, W2D_Q16_4x32} : std::vector<int>{W2D_Q8_8x32, W2D_Q16_4x32};
+  if (raw_ok) {   // raw LDS staging (whole 64-B sectors): every segment a multiple of 16 channels at a 64-B pixel stride
+    shapes.push_back(W2D_Q8_8x32_R);
+    if (Cout % 64 == 0) shapes.push_back(W2D_Q8_8x64_R);
+  }
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
   return out;
@@ -218,7 +228,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
-  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, wino2d_raw_ok(op)) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
   if (op.c3) {
     // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
     // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
@@ -382,6 +392,13 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
       const int want = w43_tile(h->opt_w43_shape) | CONV_TILE_XCD;
       if (std::find(cands.begin(), cands.end(), want) != cands.end()) op.tile = want;
     }
+  if (h->opt_w2d_shape >= 0)   // the same for the nested-Winograd tiles
+    for (OpDesc& op : P->ops) {
+      if (op.kind != OP_CONV || op.wino != 4) continue;
+      const std::vector<int> cands = conv_candidates(op);
+      const int want = h->opt_w2d_shape | CONV_TILE_W2D | CONV_TILE_XCD;
+      if (std::find(cands.begin(), cands.end(), want) != cands.end()) op.tile = want;
+    }
   P->last_use = ++h->tick;
   *out = P.get();
   h->plans.push_back(std::move(P));
@@ -537,6 +554,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->plans.clear();
       h->last_plan = nullptr;
       h->opt_wino2d = (int)value;
+    }
+  }
+  else if (!strcmp(key, "w2d_shape")) {
+    if (value < -1 || value > 15) return fail(h, FILM_ERR_INVALID, "w2d_shape: -1 (autotuned) or a Wino2dTile shape index");
+    if ((int)value != h->opt_w2d_shape) {  // plans carry the tile choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_w2d_shape = (int)value;
     }
   }
   else if (!strcmp(key, "w43_shape")) {

@@ -180,6 +180,7 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  0: never.  2: every layer that has the weight copy, on every level (tests).  Drops the cached plans.
  *   "w43_shape" n  test knob: every convolution on conv_wino43_kernel that can run tile shape n (Wino43Tile, film_kernels.h)
  *                  does, instead of the autotuned shape; -1 (default) = autotuned.  Results cannot change.  Drops the cached plans.
+ *   "w2d_shape" n  the same for conv_wino2d_kernel (Wino2dTile).
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in limits: 64 GiB of
  *                  workspace, 4 GiB per buffer read through a whole-buffer 32-bit offset); frame pairs are independent,
  *                  results do not change */

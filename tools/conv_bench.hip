@@ -85,6 +85,11 @@ static Variant variants[] = {
     F43Q8(8, 64, 2, 1, 32772), F43Q8(8, 64, 1, 2, 32772), F43N8(8, 64, 32772), F43Q8(8, 32, 1, 1, 65540), F43Q8(8, 32, 1, 1, 32772),
     W2D(8, 64, 4, 8), W2D(8, 32, 4, 8), W2D(4, 64, 4, 16), W2D(4, 32, 4, 16), W2D(8, 64, 0, 8),
     W2D(8, 64, 68, 8), W2D(8, 32, 68, 8), W2D(4, 64, 68, 16), W2D(4, 32, 68, 16),
+    W2D(8, 64, 16452, 8), W2D(8, 32, 16452, 8), W2D(8, 64, 16580, 8), W2D(8, 32, 16580, 8), W2D(8, 64, 24772, 8), W2D(8, 32, 24772, 8),
+    W2D(8, 64, 20548, 8), W2D(8, 32, 20548, 8), W2D(8, 64, 49220, 8), W2D(8, 32, 49220, 8), W2D(8, 64, 81988, 8), W2D(8, 32, 81988, 8), W2D(8, 64, 17476, 8), W2D(8, 32, 17476, 8), W2D(8, 64, 18500, 8), W2D(8, 32, 18500, 8), W2D(8, 64, 16708, 8), W2D(8, 32, 16708, 8),
+    W2D(8, 64, 147524, 8), W2D(8, 32, 147524, 8),
+    W2D(8, 64, 147780, 8), W2D(8, 32, 147780, 8), W2D(8, 64, 148036, 8), W2D(8, 32, 148036, 8), W2D(8, 64, 148548, 8), W2D(8, 32, 148548, 8), W2D(8, 64, 149572, 8), W2D(8, 32, 149572, 8), W2D(8, 64, 180292, 8), W2D(8, 32, 180292, 8), W2D(8, 64, 213060, 8), W2D(8, 32, 213060, 8),
+    W2D(8, 64, 196, 8), W2D(8, 32, 196, 8), W2D(8, 64, 8388, 8), W2D(8, 32, 8388, 8), W2D(8, 64, 4164, 8), W2D(8, 32, 4164, 8),
     W2D(8, 64, 260, 8), W2D(8, 64, 516, 8), W2D(8, 64, 1028, 8), W2D(8, 64, 2052, 8), W2D(8, 64, 3844, 8), W2D(8, 32, 260, 8), W2D(8, 32, 516, 8), W2D(8, 32, 1028, 8), W2D(8, 32, 3844, 8),
     // persistent launches (flag 524288); + 131072: the next pair's first activation chunk requested before the epilogue, + 262144: its whole prologue
     PQ(4, 64, 2, 1, 557060, 2), PN(4, 64, 557060, 2), PQ(4, 32, 1, 1, 589828, 4),
