@@ -35,6 +35,8 @@ enum { W2D_F_PFA = 128,       // touch-ahead for the activations: per chunk ever
                               // request, 16 pixels per instruction, every wave issuing its share; the staging threads then read their
                               // six pixels from LDS instead of gathering 16 B per lane from memory (3.5x fewer, fully used sectors
                               // requested; no activation registers in flight).  Needs every input segment's C % 16 == 0
+       W2D_F_B2 = 262144,     // weight slabs requested TWO chunks ahead in the same two register sets: slab j of chunk kc + 2 goes into
+                              // the registers of slab j of chunk kc as soon as its four MFMAs are issued
        W2D_F_LATE = 16384,    // with W2D_F_ILV: the transform sits on nu steps 2..5 instead of 0..3 - the item loads (the LAST requests of the
                               // previous chunk) get another half chunk before the wave waits for them
        W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
@@ -289,6 +291,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     raw_issue(0);
     if (nsc > 1) raw_issue(1);
     load_b(0, C0{});
+    if constexpr ((FLAGS & W2D_F_B2) != 0) load_b(1, C1{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (stager) {
@@ -300,6 +303,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     setup_seg();
     load_item(C0{});
     load_b(0, C0{});
+    if constexpr ((FLAGS & W2D_F_B2) != 0) load_b(1, C1{});
     // (the chunk / segment state - c0, the buffer resource - advances on EVERY thread: kept uniform it lives in scalar
     // registers; advanced under `if (stager)` it becomes a per-lane value and every buffer load turns into a waterfall loop)
     next_chunk(1);
@@ -318,7 +322,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
                                        // so the barrier that ends chunk kc + 1 publishes the buffer - first read in chunk kc + 2
       if ((kc >> 1) + 2 < nsc) raw_issue((kc >> 1) & 1);
     }
-    if constexpr ((FLAGS & W2D_DBG_NOB) == 0) load_b(kc + 1, std::integral_constant<int, 1 - PAR>{});
+    constexpr bool B2 = (FLAGS & W2D_F_B2) != 0;
+    if constexpr ((FLAGS & W2D_DBG_NOB) == 0 && !B2) load_b(kc + 1, std::integral_constant<int, 1 - PAR>{});
+    const unsigned so2 = (unsigned)(((ct * nkc + (kc + 2 < nkc ? kc + 2 : nkc - 1)) * 4 + mu) * 6) * 1024u;   // B2: slab (kc + 2)
     if constexpr (!RAW && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOALD)) == 0) load_item(par_c);   // chunk kc + 2 into the register set chunk kc came from
     if constexpr ((FLAGS & W2D_F_PFA) != 0) {   // after the real loads: in-order completion then gives the touch two chunk times
       asm volatile("" ::"v"(pfa[PAR]));
@@ -360,6 +366,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       for (int k = 0; k < 4; ++k) a[k] = COMB ? __builtin_fmaf(sgn, fb2[j & 1][k], fa[j & 1][k]) : fa[j & 1][k];
 #pragma unroll
       for (int k = 0; k < 4; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], fbg[PAR][j][k], acc[j], 0, 0, 0);
+      if constexpr (B2 && (FLAGS & W2D_DBG_NOB) == 0) fbg[PAR][j] = conv_buf_load(brsrc, bvoff, so2 + (unsigned)j * 1024u);
       if constexpr ((FLAGS & W2D_DBG_NOAST) != 0) {
         if (j == ((FLAGS & W2D_F_LATE) ? 2 : 0)) {
 #pragma unroll
@@ -389,12 +396,20 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!ILV && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0) { if (stager) store_item((kc + 1) & 1, std::integral_constant<int, 1 - PAR>{}); }   // chunk kc + 1
+    if constexpr (RAW && B2 && PAR == 0)   // the raw requests of chunk kc - 1 are older than the last 12 weight requests (in-order return):
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // landed before the barrier publishes them (also waits for the next chunk's slabs)
     if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
     if constexpr (!RAW) next_chunk(kc + 3);
   };
-  for (int kc = 0; kc < nkc; kc += 2) {
+  // pairs without a condition between the two chunks (with `if (kc + 1 < nkc)` inside the loop the compiler has to size every
+  // s_waitcnt for the path on which the odd chunk's requests were never issued - six fewer in flight, half the lookahead gone)
+  int kc = 0;
+  for (; kc + 1 < nkc; kc += 2) {
     chunk(kc, C0{});
-    if (kc + 1 < nkc) chunk(kc + 1, C1{});
+    chunk(kc + 1, C1{});
+  }
+  if constexpr (!RAW) {
+    if (kc < nkc) chunk(kc, C0{});
   }
 
   // ---- epilogue: x inverse in registers (conv_wino43's y0..y3 per mu), then the y inverse across the four mu waves of a
