@@ -42,6 +42,7 @@ enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priori
        W43_DBG_NOFRAG = 2048,
        W43_DBG_NOALOAD = 4096, // activation loads skipped, transform + LDS stores of stale registers kept
        W43_DBG_NOASTORE = 8192,// activation loads kept, transform + LDS stores skipped
+       W43_DBG_OLDLOOP = 16384,// (A/B in tools/conv_bench.hip) the PF2 K loop with the odd chunk under a condition, as before round 3
        W43_F_PF2 = 32768,      // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
        W43_F_PERSIST = 524288, // the pair loop exists (ConvParams::persist launches need it; without it a workgroup runs ONE pair and the
                                // code is the straight-line kernel: the loop costs the 128-register tile its four workgroups per CU)
@@ -369,9 +370,20 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     a_cur = a_next;
   };
   if constexpr (PF2) {
-    for (int kc = kbeg; kc < kend; kc += 2) {
-      chunk(kc, C0{});
-      if (kc + 1 < kend) chunk(kc + 1, C1{});
+    // unconditional pairs + a peeled last chunk: with `if (kc + 1 < kend)` between the two chunks the compiler sizes every
+    // s_waitcnt of the loop for the path on which the odd chunk's requests were never issued (fewer in flight = less lookahead)
+    if constexpr ((FLAGS & W43_DBG_OLDLOOP) != 0) {
+      for (int kc = kbeg; kc < kend; kc += 2) {
+        chunk(kc, C0{});
+        if (kc + 1 < kend) chunk(kc + 1, C1{});
+      }
+    } else {
+      int kc = kbeg;
+      for (; kc + 1 < kend; kc += 2) {
+        chunk(kc, C0{});
+        chunk(kc + 1, C1{});
+      }
+      if (kc < kend) chunk(kc, C0{});
     }
   } else {
     for (int kc = kbeg; kc < kend; ++kc) chunk(kc, C0{});

@@ -83,6 +83,7 @@ static Variant variants[] = {
     F43Q(4, 64, 2, 1, 260), F43Q(4, 64, 2, 1, 3844), F43N(4, 64, 32772), F43N(4, 64, 32768), F43Q(4, 64, 1, 2, 32772), F43Q(4, 64, 2, 1, 32772), F43Q(4, 32, 1, 1, 32772),
     F43Q(4, 32, 1, 1, 65540), F43N(4, 64, 65540), F43Q(4, 64, 2, 1, 65540),
     F43Q8(8, 64, 2, 1, 32772), F43Q8(8, 64, 1, 2, 32772), F43N8(8, 64, 32772), F43Q8(8, 32, 1, 1, 65540), F43Q8(8, 32, 1, 1, 32772),
+    F43Q8(8, 64, 2, 1, 49156), F43Q8(8, 64, 1, 2, 49156), F43N8(8, 64, 49156), F43Q8(8, 32, 1, 1, 49156),
     W2D(8, 64, 4, 8), W2D(8, 32, 4, 8), W2D(4, 64, 4, 16), W2D(4, 32, 4, 16), W2D(8, 64, 0, 8),
     W2D(8, 64, 68, 8), W2D(8, 32, 68, 8), W2D(4, 64, 68, 16), W2D(4, 32, 68, 16),
     W2D(8, 64, 16452, 8), W2D(8, 32, 16452, 8), W2D(8, 64, 16580, 8), W2D(8, 32, 16580, 8), W2D(8, 64, 24772, 8), W2D(8, 32, 24772, 8),
