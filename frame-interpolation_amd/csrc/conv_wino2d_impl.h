@@ -37,6 +37,9 @@ enum { W2D_F_PFA = 128,       // touch-ahead for the activations: per chunk ever
                               // requested; no activation registers in flight).  Needs every input segment's C % 16 == 0
        W2D_F_B2 = 262144,     // weight slabs requested TWO chunks ahead in the same two register sets: slab j of chunk kc + 2 goes into
                               // the registers of slab j of chunk kc as soon as its four MFMAs are issued
+       W2D_F_GRP256 = 8, W2D_F_GRP128 = 16, W2D_F_GRP512 = 32,   // block order: groups of 256 / 128 / 512 patches, inside a group one
+                              // channel block after the other (plain order = one group of ALL patches: the activations are re-read from
+                              // HBM once per channel block; a group small enough for the 256-MB Infinity Cache re-reads them from there)
        W2D_F_LATE = 16384,    // with W2D_F_ILV: the transform sits on nu steps 2..5 instead of 0..3 - the item loads (the LAST requests of the
                               // previous chunk) get another half chunk before the wave waits for them
        W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
@@ -87,6 +90,15 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const int nl = base + idx;
     bx = nl / nby;
     by = nl - bx * nby;
+  }
+  if constexpr ((FLAGS & (W2D_F_GRP256 | W2D_F_GRP128 | W2D_F_GRP512)) != 0) {
+    constexpr int G = (FLAGS & W2D_F_GRP256) ? 256 : (FLAGS & W2D_F_GRP128) ? 128 : 512;
+    const int nbx = gridDim.x, nby = gridDim.y;
+    const int lin = by * nbx + bx;
+    const int g = lin / (G * nby), r = lin - g * (G * nby);
+    const int gl = nbx - g * G < G ? nbx - g * G : G;
+    by = r / gl;
+    bx = g * G + (r - by * gl);
   }
   const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
   const int img = bx / (ntx * nty);
