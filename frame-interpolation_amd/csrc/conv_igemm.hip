@@ -139,6 +139,8 @@ static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
     case W2D_Q16_4x32: return conv_wino2d_launch<4, 32, F | W2D_SCHED, 16>(p, s);
     case W2D_Q8_8x64_R: return conv_wino2d_launch<8, 64, F | W2D_SCHED | W2D_F_RAW, 8>(p, s);
     case W2D_Q8_8x32_R: return conv_wino2d_launch<8, 32, F | W2D_SCHED | W2D_F_RAW, 8>(p, s);
+    case W2D_Q8_8x64_RM: return conv_wino2d_launch<8, 64, F | W2D_F_ILV | W2D_F_B2 | W2D_F_MIDBAR | W2D_F_RAW, 8>(p, s);
+    case W2D_Q8_8x32_M: return conv_wino2d_launch<8, 32, F | W2D_F_ILV | W2D_F_B2 | W2D_F_MIDBAR, 8>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

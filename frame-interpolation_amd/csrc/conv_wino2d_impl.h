@@ -40,6 +40,10 @@ enum { W2D_F_PFA = 128,       // touch-ahead for the activations: per chunk ever
        W2D_F_GRP256 = 8, W2D_F_GRP128 = 16, W2D_F_GRP512 = 32,   // block order: groups of 256 / 128 / 512 patches, inside a group one
                               // channel block after the other (plain order = one group of ALL patches: the activations are re-read from
                               // HBM once per channel block; a group small enough for the 256-MB Infinity Cache re-reads them from there)
+       W2D_F_MIDBAR = 524288, // (with ILV and B2) THREE activation stages and the chunk's one barrier behind nu step 3 instead of behind step 5:
+                              // the next stage is complete and published two steps before the chunk ends, so the first fragment
+                              // of chunk kc + 1 is read during step 5 of chunk kc - no LDS round trip behind the barrier, where both
+                              // waves of a SIMD would sit it out together (64-channel tile: they belong to the same workgroup)
        W2D_F_LATE = 16384,    // with W2D_F_ILV: the transform sits on nu steps 2..5 instead of 0..3 - the item loads (the LAST requests of the
                               // previous chunk) get another half chunk before the wave waits for them
        W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
@@ -63,6 +67,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   static_assert(ITEMS <= NT, "staging items");
   constexpr unsigned OOB = 0xFFFFFFFFu;
   constexpr bool RAW = (FLAGS & W2D_F_RAW) != 0;
+  constexpr bool MID = (FLAGS & W2D_F_MIDBAR) != 0;
+  constexpr int NST = MID ? 3 : 2;             // activation stages
+  static_assert(!MID || ((FLAGS & W2D_F_ILV) && (FLAGS & W2D_F_B2)), "W2D_F_MIDBAR needs W2D_F_ILV and W2D_F_B2");
   constexpr int PW = PXW + 2;                  // halo pixels per patch row
   constexpr int NPIX = HR * PW;
   constexpr int NI = (NPIX + 15) / 16;         // raw requests (16 pixels x 64 B = 1 KB of LDS each) per 16-channel super-chunk
@@ -230,7 +237,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   };
   auto raw_issue = [&](int buf) {   // the next super-chunk (16 channels) of the patch -> raw buffer `buf`; advances the raw cursor
     const unsigned so = (unsigned)rc0 * 4u;
-    const unsigned base = lds0 + (unsigned)(2 * A_STAGE + buf * R_STAGE) * 4u + (unsigned)wv * 1024u;
+    const unsigned base = lds0 + (unsigned)(NST * A_STAGE + buf * R_STAGE) * 4u + (unsigned)wv * 1024u;
 #pragma unroll
     for (int n = 0; n < IPW; ++n)
       asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(base + (unsigned)(NW * n) * 1024u), "v"(rvoff[n]), "s"(rrsrc), "s"(so)
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   }
   const bf4* const smem4r = reinterpret_cast<const bf4*>(smem);
   auto raw_read = [&](bf4 (&rv)[6], int buf, int h) {
-    const unsigned b4 = (unsigned)(2 * A_STAGE + buf * R_STAGE) / 4u, hx = (unsigned)h << 3;
+    const unsigned b4 = (unsigned)(NST * A_STAGE + buf * R_STAGE) / 4u, hx = (unsigned)h << 3;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       asm volatile("" : "+v"(xj[j]));   // opaque: otherwise the four (buffer, h) address sets are hoisted out of the K loop (24 registers)
@@ -297,6 +304,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // return zero without touching memory - so that all waves have the SAME number of loads in flight: with the loads under
   // `if (stager)` the compiler has to place one s_waitcnt vmcnt(n) valid for both paths, and the staging waves then wait
   // for the weight loads they issued a moment ago (a full L2 latency per chunk)
+  bf4 fa[2], fb2[2];   // A fragments (two halo rows) of the current / next nu step
+  int st_cur = 0;      // activation stage of the current chunk
   const int nsc = nkc / 2;   // W2D_F_RAW: super-chunks
   if constexpr (RAW) {
     raw_setup_seg();
@@ -324,10 +333,15 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     next_chunk(2);
     __syncthreads();
   }
+  if constexpr (MID) {   // step 0 of chunk 0
+    fa[0] = reinterpret_cast<const bf4*>(smem)[ad_a];
+    fb2[0] = reinterpret_cast<const bf4*>(smem)[ad_b];
+  }
 
   auto chunk = [&](int kc, auto par_c) {
     constexpr int PAR = decltype(par_c)::value;
-    const int sa = (kc & 1) * A_STAGE4;
+    const int st_next = st_cur + 1 == NST ? 0 : st_cur + 1;
+    const int sa = st_cur * A_STAGE4;
     if constexpr (RAW && PAR == 1 && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOALD)) == 0) {   // odd chunk: raw buffer (kc >> 1) & 1 was last read in chunk kc - 1; refill it with super-chunk
                                        // (kc >> 1) + 2.  Issued BEFORE the weight requests: the compiler's vmcnt counts for those stay
                                        // exact, and the wait for the last weight slab of chunk kc + 1 covers these (in-order return),
@@ -348,7 +362,6 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       pfb[PAR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)pfb_off, (int)so3, 0));
     }
     __builtin_amdgcn_sched_barrier(0);   // the twelve requests of the chunk go out first, in this order (the s_waitcnt counts below rely on it)
-    bf4 fa[2], fb2[2];
     bf4 sv[6];   // W2D_F_ILV: the item of chunk kc + 1, transformed two channels per nu step
     constexpr bool ILV = (FLAGS & W2D_F_ILV) != 0 && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0;
     auto xform = [&](int c) {
@@ -363,15 +376,20 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       sv[4][c] = t3 - t4;
       sv[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
     };
-    float* const As_next = smem + ((kc + 1) & 1) * A_STAGE + a_lds;
-    fa[0] = smem4[sa + ad_a];
+    float* const As_next = smem + st_next * A_STAGE + a_lds;
     constexpr bool COMB = (FLAGS & W2D_DBG_NOCOMB) == 0;
-    if constexpr (COMB) fb2[0] = smem4[sa + ad_b];
+    if constexpr (!MID) {
+      fa[0] = smem4[sa + ad_a];
+      if constexpr (COMB) fb2[0] = smem4[sa + ad_b];
+    }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       if (j + 1 < 6) {
         fa[(j + 1) & 1] = smem4[sa + ad_a + (j + 1) * (QW * 2)];
         if constexpr (COMB) fb2[(j + 1) & 1] = smem4[sa + ad_b + (j + 1) * (QW * 2)];
+      } else if constexpr (MID) {   // step 0 of the next chunk: its stage was published by the barrier behind step 3
+        fa[0] = smem4[st_next * A_STAGE4 + ad_a];
+        if constexpr (COMB) fb2[0] = smem4[st_next * A_STAGE4 + ad_b];
       }
       bf4 a;
 #pragma unroll
@@ -393,25 +411,35 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       if constexpr (ILV) {
         if (stager) {
           constexpr int J0 = (FLAGS & W2D_F_LATE) ? 2 : 0;
-          if (j == J0) { xform(0); xform(1); }
-          if (j == J0 + 1) { xform(2); xform(3); }
-          if (j == J0 + 2) {
+          // transform steps / store steps: behind the raw read of step 0 (RAW) and in front of the barrier behind step 3 (MID)
+          constexpr int JX0 = MID ? (RAW ? 1 : 0) : J0, JX1 = JX0 + 1, JS0 = MID ? 2 : J0 + 2, JS1 = JS0 + 1;
+          if (j == JX0) { xform(0); xform(1); }
+          if (j == JX1) { xform(2); xform(3); }
+          if (j == JS0) {
 #pragma unroll
             for (int nu = 0; nu < 3; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
           }
-          if (j == J0 + 3) {
+          if (j == JS1) {
 #pragma unroll
             for (int nu = 3; nu < 6; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
           }
         }
       }
+      if constexpr (MID) {
+        if (j == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (RAW && PAR == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // the raw requests of chunk kc - 1 (ten weight requests younger)
+          __syncthreads();
+        }
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (!ILV && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0) { if (stager) store_item((kc + 1) & 1, std::integral_constant<int, 1 - PAR>{}); }   // chunk kc + 1
-    if constexpr (RAW && B2 && PAR == 0)   // the raw requests of chunk kc - 1 are older than the last 12 weight requests (in-order return):
+    if constexpr (RAW && B2 && PAR == 0 && !MID)   // the raw requests of chunk kc - 1 are older than the last 12 weight requests (in-order return):
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // landed before the barrier publishes them (also waits for the next chunk's slabs)
-    if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
+    if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0 && !MID) __syncthreads();
     if constexpr (!RAW) next_chunk(kc + 3);
+    st_cur = st_next;
   };
   // pairs without a condition between the two chunks (with `if (kc + 1 < nkc)` inside the loop the compiler has to size every
   // s_waitcnt for the path on which the odd chunk's requests were never issued - six fewer in flight, half the lookahead gone)
@@ -428,6 +456,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // channel tile through LDS, one x position per round: waves mu = 1, 2 publish, mu = 0 forms row 2k = (m0 + m1) + m2,
   // mu = 3 forms row 2k + 1 = (m1 - m2) - m3.  C/D layout of the 32x32 MFMA: col = lane & 31 (cout), row = (r&3) + 8*(r>>2)
   // + 4*(lane>>5) = unit.
+  if constexpr (MID) __syncthreads();   // no barrier behind the last chunk's steps 4 / 5 (fragment reads): the exchange buffer overlays the stages
   float* const xbuf = smem;                                  // [ng][which: mu 1 / mu 2][16 regs][64 lanes]
   const int n = n0 + ng * 32 + l31;
   const float bv = p.bias[n];
@@ -469,11 +498,11 @@ template <int TH, int BN, int FLAGS, int QW = 8>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   constexpr int NWL = 4 * (BN / 32), NIL = ((TH + 2) * (4 * QW + 2) + 15) / 16;
   constexpr size_t r_bytes = (FLAGS & W2D_F_RAW) ? 2 * (size_t)(((NIL + NWL - 1) / NWL) * NWL) * 1024 : 0;
-  constexpr size_t a_bytes = 2 * (size_t)(TH + 2) * 6 * QW * 8 * sizeof(float) + r_bytes;
+  constexpr size_t a_bytes = ((FLAGS & W2D_F_MIDBAR) ? 3 : 2) * (size_t)(TH + 2) * 6 * QW * 8 * sizeof(float) + r_bytes;
   constexpr size_t x_bytes = (size_t)(BN / 32) * 2 * 16 * 64 * sizeof(float);
   constexpr size_t lds = a_bytes > x_bytes ? a_bytes : x_bytes;
   constexpr int NT = 4 * (BN / 32) * 64;
-  static_assert(lds <= 80 * 1024, "LDS (two workgroups per CU with BN = 32)");
+  static_assert(lds <= (BN == 32 ? 80 : 160) * 1024, "LDS (two workgroups per CU with BN = 32)");
   if constexpr ((FLAGS & W2D_F_RAW) != 0) {
     if (p.Ctot % 16) return hipErrorInvalidValue;
     for (int i = 0; i < p.nseg; ++i)

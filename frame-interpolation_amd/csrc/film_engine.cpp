@@ -173,9 +173,10 @@ static bool wino2d_raw_ok(const OpDesc& op) {
 
 std::vector<int> wino2d_candidates(int Cout, bool raw_ok) {
   std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W2D_Q8_8x64, W2D_Q8_8x32, W2D_Q16_4x64, W2D_Q16_4x32} : std::vector<int>{W2D_Q8_8x32, W2D_Q16_4x32};
+  shapes.push_back(W2D_Q8_8x32_M);
   if (raw_ok) {   // raw LDS staging (whole 64-B sectors): every segment a multiple of 16 channels at a 64-B pixel stride
     shapes.push_back(W2D_Q8_8x32_R);
-    if (Cout % 64 == 0) shapes.push_back(W2D_Q8_8x64_R);
+    if (Cout % 64 == 0) { shapes.push_back(W2D_Q8_8x64_R); shapes.push_back(W2D_Q8_8x64_RM); }
   }
   std::vector<int> out;
   for (int sh : shapes) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }

@@ -365,7 +365,7 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
     got, _ = _check_stages(eng, opt, wts, x0, x1)
     taps = {k: eng.tap(k) for k in ('feat1', 'aligned0', 'aligned1')}
     used = set()
-    for shape in range(6):        # Wino2dTile: 4 / 5 = the raw-LDS-staging tiles (buffer_load ... lds)
+    for shape in range(8):        # Wino2dTile: 4 / 5 = the raw-LDS-staging tiles (buffer_load ... lds), 6 / 7 = three stages + mid-chunk barrier
         eng.set_option('w2d_shape', shape)
         tiles = {o['tile'] & 15 for o in eng.plan(b, h, w)['ops'] if o['kind'] == 'conv_mfma' and (o['tile'] & 8192)}
         if shape not in tiles:
@@ -376,7 +376,7 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
         for k, v in taps.items():
             assert np.array_equal(eng.tap(k), v), (shape, k)
     print('nested-Winograd tile shapes exercised:', sorted(used))
-    assert {1, 3, 5} <= used, used
+    assert {1, 3, 5, 6, 7} <= used, used
     eng.set_option('w2d_shape', -1)
     eng.set_option('wino2d', 0)
     assert sum(1 for op in eng.plan(b, h, w)['ops'] if op.get('wino') == 4) == 0

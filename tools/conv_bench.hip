@@ -92,6 +92,7 @@ static Variant variants[] = {
     W2D(8, 64, 147780, 8), W2D(8, 32, 147780, 8), W2D(8, 64, 148036, 8), W2D(8, 32, 148036, 8), W2D(8, 64, 148548, 8), W2D(8, 32, 148548, 8), W2D(8, 64, 149572, 8), W2D(8, 32, 149572, 8), W2D(8, 64, 180292, 8), W2D(8, 32, 180292, 8), W2D(8, 64, 213060, 8), W2D(8, 32, 213060, 8),
     W2D(8, 64, 278596, 8), W2D(8, 32, 278596, 8), W2D(8, 64, 409668, 8), W2D(8, 32, 409668, 8),
     W2D(8, 64, 409664, 8), W2D(8, 32, 409664, 8), W2D(8, 64, 409672, 8), W2D(8, 32, 409672, 8), W2D(8, 64, 409680, 8), W2D(8, 32, 409680, 8), W2D(8, 64, 409696, 8), W2D(8, 32, 409696, 8), W2D(8, 64, 278592, 8), W2D(8, 32, 278592, 8), W2D(8, 64, 278600, 8), W2D(8, 32, 278600, 8), W2D(8, 64, 278608, 8), W2D(8, 32, 278608, 8), W2D(8, 64, 278624, 8), W2D(8, 32, 278624, 8),
+    W2D(8, 64, 786496, 8), W2D(8, 32, 786496, 8), W2D(8, 64, 786500, 8), W2D(8, 32, 786500, 8), W2D(8, 64, 917568, 8), W2D(8, 64, 917572, 8), W2D(4, 64, 786500, 16), W2D(4, 32, 786500, 16), W2D(4, 64, 278596, 16), W2D(4, 32, 278596, 16),
     W2D(8, 64, 196, 8), W2D(8, 32, 196, 8), W2D(8, 64, 8388, 8), W2D(8, 32, 8388, 8), W2D(8, 64, 4164, 8), W2D(8, 32, 4164, 8),
     W2D(8, 64, 260, 8), W2D(8, 64, 516, 8), W2D(8, 64, 1028, 8), W2D(8, 64, 2052, 8), W2D(8, 64, 3844, 8), W2D(8, 32, 260, 8), W2D(8, 32, 516, 8), W2D(8, 32, 1028, 8), W2D(8, 32, 3844, 8),
     // persistent launches (flag 524288); + 131072: the next pair's first activation chunk requested before the epilogue, + 262144: its whole prologue
