@@ -446,8 +446,8 @@ def main():
         peak = {0: PEAK_FP32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS / 6, 2: PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
         roofline = {
             'bound': 'mfma',
-            'kernel': ('conv class = conv_wino43_kernel / conv_wino_kernel / conv_halo_kernel / conv_buf_kernel (fp32 v_mfma_f32_32x32x2_f32); '
-                       '`achieved` / `frac` count the FLOPs the matrix pipe executes (Winograd F(4,3) layers x1/2, F(2,3) x2/3, folded 2x2 layers x9/16 '
+            'kernel': ('conv class = conv_wino2d_kernel / conv_wino43_kernel / conv_buf_kernel / conv_c3_kernel (fp32 v_mfma_f32_32x32x2_f32); '
+                       '`achieved` / `frac` count the FLOPs the matrix pipe executes (nested Winograd F(4,3)x x F(2,3)y layers x1/3, F(4,3) x1/2, F(2,3) x2/3, folded 2x2 layers x9/16 '
                        'of the direct convolution)')
                       if not args.precision else
                       ('conv class in the opt-in split mode = conv_winox3_kernel / conv_halo_split_kernel '
