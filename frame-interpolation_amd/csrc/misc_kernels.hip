@@ -314,6 +314,11 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   if (x >= p.W || g >= G) return;
   const int64_t rowpitch = (int64_t)p.W * p.sstride;
   const float* const img = p.src + b * p.H * rowpitch + g * 4;
+  // the flows of all eight rows first: the second half's flow round trip then overlaps the first half's corner loads instead of
+  // following them (two dependent memory round trips per four rows are what bounds this kernel)
+  float2 flw[WARP_ROWS];
+#pragma unroll
+  for (int k = 0; k < WARP_ROWS; ++k) flw[k] = warp_flow_at(p, b, min(yb + k, p.H - 1), x);
 #pragma unroll
   for (int k0 = 0; k0 < WARP_ROWS; k0 += 4) {
     if (yb + k0 >= p.H) break;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int y = min(yb + k0 + j, p.H - 1);     // rows past the end repeat the last one (loads only, no store)
-      const float2 fl = warp_flow_at(p, b, y, x);
+      const float2 fl = flw[k0 + j];
       if (p.flow_out != nullptr && g == 0 && yb + k0 + j < p.H)
         reinterpret_cast<float2*>(p.flow_out)[(b * p.H + y) * p.W + x] = fl;
       const float qy = (float)y + p.fscale * fl.y;
