@@ -160,8 +160,10 @@ struct Planner {
     // Nested F(4,3)x x F(2,3)y (conv_wino2d_kernel, 1.5x fewer MFMAs again): the deep-K layers (K >= 384: the first layer of
     // every flow predictor but level 0's, the wide layer of every decoder level but level 0's, cfeat_conv_7) on levels large
     // enough to fill the chip without split-K.  A family of its own (a function of the layer and the level size only).
-    if (L.w2d_off >= 0 && w2d_ok && !any_up && h->opt_precision == 0 &&
-        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && op.wino == 3 && h->opt_wino == 1 && px >= 8192)))
+    // (Round 3, second half: no longer tied to the 1-D kernel's own thresholds - a 64-channel layer needed 30 000 pixels for those,
+    // which left K = 384 -> 64 of flow level 1 on the direct kernel for 448x256 and 256x256 frames.)
+    if (L.w2d_off >= 0 && w2d_ok && !any_up && h->opt_precision == 0 && op.split == 0 &&
+        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= 8192)))
       op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
