@@ -14,6 +14,8 @@ def family(op):
     t = op['tile']
     if op['kind'] != 'conv_mfma':
         return op['kind']
+    if t & 8192:
+        return 'conv_wino2d F(4,3)x x F(2,3)y'
     if t & 1024:
         return 'conv_foldx3'
     if t & 256:
@@ -23,7 +25,7 @@ def family(op):
     if t & 64:
         return 'conv_halo'
     if t & 32:
-        return 'conv_igemm (3-channel)'
+        return 'conv_c3 (3-channel, direct)' if (t & 15) == 7 else 'conv_igemm (3-channel)'
     return 'conv_buf' + (' (4 phases)' if op.get('fold') else '')
 
 
