@@ -1,4 +1,7 @@
 // conv_igemm_impl.h -- the implicit-GEMM convolution kernel template (see conv_igemm.hip for the overview).
+// Round 1's general kernel.  What still uses it: the first-layer (3-channel, [48][Cout] weights) mode for Cout other than 32 / 64
+// (conv_c3_kernel covers those two), and tools/conv_bench.hip as the A/B baseline; every other layer runs conv_buf_kernel or one of
+// the Winograd kernels.
 //
 // Template knobs (all compile time):
 //   BM x BN        workgroup tile (pixels x output channels)
