@@ -174,7 +174,7 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.
- *   "wino2d"  0/1/2  1 (default): the deep-K 3x3 convolutions (>= 384 input channels) of levels with >= 8192 pixels run the nested
+ *   "wino2d"  0/1/2  1 (default): the deep-K 3x3 convolutions (>= 208 input channels, or 128 -> 32) of levels with >= 8192 pixels run the nested
  *                  Winograd form F(4,3) along x times F(2,3) along y (conv_wino2d_kernel: 3 multiplies per output where the 1-D
  *                  F(4,3) kernel spends 4.5 and the direct convolution 9; fp32 throughout, rounding at the level of the 1-D form).
  *                  0: never.  2: every layer that has the weight copy, on every level (tests).  Drops the cached plans.
