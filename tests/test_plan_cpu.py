@@ -443,3 +443,36 @@ def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_w
     fresh.set_weights(w2)
     fresh.plan(1, 128, 96)
     assert np.array_equal(after, fresh.export_layouts())
+
+
+def test_nested_winograd_rule_is_a_function_of_layer_and_level_size():
+    """conv_wino2d_kernel runs the layers that have the nested copy (K >= 208, or 128 -> 32) on levels with >= 8192 pixels - whatever
+    the batch size, and (round 3) also on small frames, where the 1-D kernel's own thresholds used to keep the 64-channel layers
+    on the direct kernel.  Pooled sub-extractor stages and levels below 8192 pixels never get it; "w2d_shape" forces one tile shape
+    where it fits and is validated."""
+    from film_hip.engine import FilmEngine, FilmError
+    from film_hip.options import PUBLISHED
+    eng = FilmEngine(PUBLISHED, device=-1)
+
+    def nested(b, h, w):
+        return sorted((o['tag'], o['H'], o['W']) for o in eng.plan(b, h, w)['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4)
+
+    for (h, w) in ((256, 256), (256, 448), (576, 960)):
+        one = nested(1, h, w)
+        assert one == nested(3, h, w)                                  # never a function of the batch
+        for tag, hh, ww in one:
+            assert hh * ww >= 8192 and '+pool' not in tag, (tag, hh, ww)
+    small = [t for t, _, _ in nested(1, 256, 256)]
+    assert any('flow_predictor_1/conv_0' in t for t in small) and any('flow_predictor_0/conv_0' in t for t in small), small
+    assert len(nested(4, 576, 960)) == 14
+    # every nested op of a plan also satisfies the rule the other way round: deep K or the 128 -> 32 layer
+    for o in eng.plan(1, 256, 448)['ops']:
+        if o['kind'] == 'conv_mfma' and o['wino'] == 4:
+            assert o['Ctot'] >= 208 or (o['Ctot'] >= 128 and o['Cout'] == 32), o['tag']
+    # the tile knob: a shape every nested layer can run is taken (32-channel Q8 tile = 1); out-of-range values are refused
+    eng.set_option('w2d_shape', 1)
+    tiles = {o['tile'] for o in eng.plan(1, 256, 448)['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4}
+    assert tiles == {1 | 8192 | 16}, tiles
+    eng.set_option('w2d_shape', -1)
+    with pytest.raises(FilmError):
+        eng.set_option('w2d_shape', 99)
