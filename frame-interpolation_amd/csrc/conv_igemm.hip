@@ -126,21 +126,11 @@ static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
-// scheduling flags of every conv_wino2d_kernel tile (none of them changes a sum): transform interleaved with the MFMA loop, on
-// its late nu steps; weight slabs requested two chunks ahead (profiles/r03_conv_bench_w2d_b2.log: -5..-11 % per layer)
-constexpr int W2D_SCHED = W2D_F_ILV | W2D_F_LATE | W2D_F_B2;
-
 template <int F>
 static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
-    case W2D_Q8_8x64: return conv_wino2d_launch<8, 64, F | W2D_SCHED, 8>(p, s);
-    case W2D_Q8_8x32: return conv_wino2d_launch<8, 32, F | W2D_SCHED, 8>(p, s);
-    case W2D_Q16_4x64: return conv_wino2d_launch<4, 64, F | W2D_SCHED, 16>(p, s);
-    case W2D_Q16_4x32: return conv_wino2d_launch<4, 32, F | W2D_SCHED, 16>(p, s);
-    case W2D_Q8_8x64_R: return conv_wino2d_launch<8, 64, F | W2D_SCHED | W2D_F_RAW, 8>(p, s);
-    case W2D_Q8_8x32_R: return conv_wino2d_launch<8, 32, F | W2D_SCHED | W2D_F_RAW, 8>(p, s);
-    case W2D_Q8_8x64_RM: return conv_wino2d_launch<8, 64, F | W2D_F_ILV | W2D_F_B2 | W2D_F_MIDBAR | W2D_F_RAW, 8>(p, s);
-    case W2D_Q8_8x32_M: return conv_wino2d_launch<8, 32, F | W2D_F_ILV | W2D_F_B2 | W2D_F_MIDBAR, 8>(p, s);
+    case W2D_8x64: return conv_wino2d_launch<64, F>(p, s);
+    case W2D_8x32: return conv_wino2d_launch<32, F>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -1,90 +1,90 @@
-// conv_wino2d_impl.h -- 3x3 Conv2D('same') + bias + leaky_relu with a NESTED Winograd transform, fp32 MFMA:
-// F(4,3) along x (as conv_wino43_impl.h) x F(2,3) along y.  Per output UNIT of 2 rows x 4 pixels and per (ci, co):
-// 4 (mu) x 6 (nu) = 24 multiplies for 8 outputs = 3 per output, where the 1-D F(4,3) form spends 18 / 4 = 4.5 and the
-// direct convolution 9: 1.5x fewer v_mfma_f32_32x32x2_f32 than conv_wino43_kernel.
+// conv_wino2d_impl.h -- 3x3 Conv2D('same') + bias + leaky_relu with a NESTED Winograd transform, fp32 MFMA: F(4,3) along x x F(2,3)
+// along y.  Per output UNIT of 2 rows x 4 pixels and per (ci, co): 4 (mu) x 6 (nu) = 24 multiplies for 8 outputs = 3 per output
+// (1-D F(4,3): 4.5, direct: 9).  Round 3's kernel (conv_wino2d_r3_kernel, tools/retired/conv_wino2d_r3_impl.h) with both activation transforms
+// moved to the FRAGMENT side, and a new epilogue:
 //
-//   d (4 rows x 6 pixels)  --x: F(4,3) B^T per row-->  v[r][nu]  --y: F(2,3) B^T-->  V[mu][nu]:
-//       V[0] = v[0] - v[2]     V[1] = v[1] + v[2]     V[2] = v[2] - v[1]     V[3] = v[1] - v[3]
-//   weights  U[mu][nu]: u_nu(dy) = the F(4,3) transform of kernel row dy (as in conv_wino43_impl.h), then along dy
+//   d (4 rows x 6 pixels)  --y: F(2,3) B^T-->  e[mu] = d[ra] +- d[rb]  --x: F(4,3) B^T-->  V[mu][nu]
+//       mu 0: d[0] - d[2]     mu 1: d[1] + d[2]     mu 2: d[2] - d[1]     mu 3: d[1] - d[3]
+//   weights  U[mu][nu] (film_layers.cpp packs them): F(4,3) of kernel row dy along x, then along dy
 //       U[0] = u(0)    U[1] = ((u(0) + u(2)) + u(1)) / 2    U[2] = ((u(0) + u(2)) - u(1)) / 2    U[3] = u(2)
-//   M[mu][nu] = sum_ci V[mu][nu] U[mu][nu]  (24 independent GEMMs),  x inverse per mu (conv_wino43's y0..y3), then
+//   M[mu][nu] = sum_ci V[mu][nu] U[mu][nu]  (24 independent GEMMs), x inverse per mu, then
 //       row 2k = (M'[0] + M'[1]) + M'[2]      row 2k+1 = (M'[1] - M'[2]) - M'[3]
 //
-// Mapping (what makes it affordable - the 2-D form was sized and rejected twice because the activation staging per MFMA
-// grows; here it does not):
-//   * the activation staging is conv_wino43_kernel's, unchanged: the x-transformed halo rows of a K chunk go to LDS once,
-//     [halo row][nu 6][quad][8] - 10 rows per 8 output rows with the 32-pixel x 8-row patch;
-//   * the y transform costs NO extra staging: a wave owns ONE mu (and 32 output channels, all six nu planes: 96 accumulator
-//     registers) and forms its A fragment as (row a) +- (row b) of that LDS image on the way into the MFMA - two
-//     ds_read_b128 and four v_fma per four MFMAs;
-//   * a (mu, channel tile) weight slab has exactly one consumer wave, so the weights skip LDS: [Cout / 32][chunk][mu][nu]
-//     [K half][32 channels][4] in memory = one fully coalesced 1 KB read per (mu, nu) step, requested a chunk ahead;
-//   * one barrier per chunk (24 MFMAs per wave); the epilogue exchanges the mu planes through LDS in four rounds.
-// fp32 throughout.  A different summation family from the 1-D kernels (not bit-identical to them).
+// What the measurements of rounds 3 / 4 said, and what the kernel does about it (profiles/r04_w2d_*.log):
+//   * conv_wino2d_r3_kernel staged a K chunk in two hops (raw patch -> 160 threads transform along x -> LDS image -> every wave combines
+//     two rows of it along y): the waves that own the staging threads are late at the chunk's barrier.  Here nobody stages: the RAW
+//     halo patch of a 16-channel super-chunk goes to LDS by DMA (`buffer_load_dwordx4 ... lds`: no registers, no VALU), three stages,
+//     its requests spread over the MFMA gaps of two chunks (a request costs 60-180 cycles of issue), four chunks ahead of its first
+//     reader, published by ONE barrier per super-chunk (48 MFMAs per wave).  A wave (one mu, 32 output channels, six nu planes: 96
+//     accumulator registers) reads the six raw pixels of its two halo rows (12 ds_read_b128 per chunk - as many as the transformed
+//     rows cost before) and transforms them in registers, every wave the same work, in the MFMA gaps of the previous chunk.
+//   * The loop is ISSUE bound (two waves per SIMD: every vector instruction beside the MFMAs shows; PMC: MFMA pipe 63 % busy with
+//     the x-then-y order of conv_wino2d_r3_kernel = 120 VALU instructions per 24 MFMAs, 70 % with none).  So the y combine comes FIRST
+//     - on the raw rows, 24 instructions - and then ONE x transform (48): 72 per chunk.  Same linear map, another operation order:
+//     this kernel is its own summation family (W2D_F_XFIRST keeps the old order - and with it conv_wino2d_r3_kernel's bits - for
+//     tools/w2d_bench.hip, which checks the loop against that kernel; the planner never uses it).
+//   * MFMA order inside a chunk: nu pairs, the two accumulators of a pair alternating (an MFMA never follows the one it depends on:
+//     fillers between them cost issue slots, not forwarding stalls); the weight slab of a plane goes straight from L2 into registers
+//     ([Cout / 32][chunk][mu][nu][K half][32][4] = one coalesced 1 KB read per (mu, nu) step) and is re-requested for chunk kc + 2
+//     into the same registers right behind its last MFMA.
+//   * conv_wino2d_r3_kernel's epilogue cost 26 000 cycles per workgroup (s_memtime; the K loop of a K = 208 layer: 101 000): 128 dword
+//     stores per 32-channel tile from two of the four mu waves, in four exchange rounds with two barriers each.  The MFMA operands
+//     are swapped here (A = weights, B = activations: C^T, the same sums) so that a lane holds four CONSECUTIVE channels of a unit;
+//     the x-inverted planes go through LDS once per x position (double buffered: one barrier per round), every thread combines the
+//     four mu planes of one (unit, 4-channel group) into both output rows and stores them as dwordx4: 32 stores of 1 KB per tile
+//     (8 pixels x 128 contiguous bytes each), all waves storing.
+//
+// LDS layout of a stage (bytes): halo row r at r * 2368; in a row pixel px = 4 k + m, 16-byte piece c of its 64 bytes at
+// m * 576 + c * 144 + k * 16 (k = 0..8: nine slots per (m, piece), the ninth unused for m = 2, 3).  A fragment read is
+// (halo row 2 ur + ro, pixel 4 lq + j, piece 2 h + half) = lane base + an immediate, and conflict free: the eight quads of a
+// unit row are 128 contiguous bytes and two rows down is 4736 = 128 (mod 256) bytes away - each ds_read_b128 lane group
+// (MI355X: {0-3, 12-15, 20-27}, ...) covers all 64 banks once.  The DMA writes 64 consecutive 16-byte slots per request; which
+// (pixel, piece) a lane fetches is free, so the layout costs nothing on the write side (out-of-image and padding slots carry an
+// out-of-range offset and receive zeros = the 'same' padding).
+//
+// Needs every input segment's C % 16 == 0 (16-byte aligned pixels), Ctot % 16 == 0, a 16-byte aligned output slice.  fp32 throughout.
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W2D_F_PFA = 128,       // touch-ahead for the activations: per chunk every staging thread reads ONE dword of the next 128-B line of
-                              // one of its pixels, issued after the chunk's real loads (in-order vmcnt: it has two chunk times to
-                              // land) - the item loads three to six chunks later then hit L2 instead of waiting for HBM
-       W2D_F_PFB = 8192,      // the same for the weight slab of chunk kc + 3 (48 lines of 128 B: one dword load on 48 lanes)
-       W2D_DBG_AHOT = 4096,   // timing ablation: every activation load from the first 64 KB of the tensor (same requests, all cache hits)
-       W2D_DBG_NOAST = 32768, // timing ablation: item loads issued, no transform / LDS store
-       W2D_DBG_NOALD = 65536, // timing ablation: transform + LDS store of whatever the registers hold, no item loads
-       W2D_F_RAW = 131072,    // the halo patch goes to LDS RAW first: buffer_load_dwordx4 ... lds, 16 channels (one 64-B sector per pixel) per
-                              // request, 16 pixels per instruction, every wave issuing its share; the staging threads then read their
-                              // six pixels from LDS instead of gathering 16 B per lane from memory (3.5x fewer, fully used sectors
-                              // requested; no activation registers in flight).  Needs every input segment's C % 16 == 0
-       W2D_F_B2 = 262144,     // weight slabs requested TWO chunks ahead in the same two register sets: slab j of chunk kc + 2 goes into
-                              // the registers of slab j of chunk kc as soon as its four MFMAs are issued
-       W2D_F_GRP256 = 8, W2D_F_GRP128 = 16, W2D_F_GRP512 = 32,   // block order: groups of 256 / 128 / 512 patches, inside a group one
-                              // channel block after the other (plain order = one group of ALL patches: the activations are re-read from
-                              // HBM once per channel block; a group small enough for the 256-MB Infinity Cache re-reads them from there)
-       W2D_F_MIDBAR = 524288, // (with ILV and B2) THREE activation stages and the chunk's one barrier behind nu step 3 instead of behind step 5:
-                              // the next stage is complete and published two steps before the chunk ends, so the first fragment
-                              // of chunk kc + 1 is read during step 5 of chunk kc - no LDS round trip behind the barrier, where both
-                              // waves of a SIMD would sit it out together (64-channel tile: they belong to the same workgroup)
-       W2D_F_LATE = 16384,    // with W2D_F_ILV: the transform sits on nu steps 2..5 instead of 0..3 - the item loads (the LAST requests of the
-                              // previous chunk) get another half chunk before the wave waits for them
-       W2D_F_ILV = 64,        // the transform + LDS stores of the next chunk's item are spread over the nu steps of the MFMA loop (in the
-                              // gaps between MFMA groups) instead of sitting between the last MFMA and the barrier
-       W2D_DBG_NOB = 256,     // timing ablations (tools/conv_bench.hip only; results are wrong on purpose): no weight loads in the K loop
-       W2D_DBG_NOCOMB = 512,  // no second fragment read / no y combine
-       W2D_DBG_NOA = 1024,    // no activation staging in the K loop
-       W2D_DBG_NOBAR = 2048 };// no barrier in the K loop
+enum { W2D_F_XFIRST = 32,      // tools only: x transform per row, then the y combine (120 VALU per chunk; the bits of conv_wino2d_r3_kernel)
+       W2D_DBG_NOXF = 256,     // timing ablations (tools only; results are wrong on purpose): no transforms (raw pixels as fragments)
+       W2D_DBG_NODMA = 512,    // no DMA requests in the K loop
+       W2D_DBG_NOB = 1024,     // no weight requests in the K loop
+       W2D_DBG_NOBAR = 2048,   // no barrier in the K loop
+       W2D_DBG_NORD = 4096,    // no fragment reads in the K loop
+       W2D_DBG_TIME = 8192 };  // wave 0 of every workgroup writes s_memtime at kernel entry / first MFMA / last MFMA / exit to
+                               // p.part[workgroup * 8 ..] (tools/w2d_bench.hip prints the averages)
 
-template <int TH, int BN, int FLAGS, int QW = 8>
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the MFMA gaps of a chunk, every index a compile-time constant
+template <class F, int... G>
+__device__ __forceinline__ void w2d_for_each(F&& f, std::integer_sequence<int, G...>) { (f(std::integral_constant<int, G>{}), ...); }
+
+// BN = 32 NG output channels per workgroup, one wave per (mu, 32 channels): 4 NG waves, two waves per SIMD either way (BN = 64: one
+// workgroup of 8 waves per CU; BN = 32: two of 4 - their prologues / epilogues overlap the other's K loop: the usual winner)
+template <int BN, int FLAGS>
 __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_wino2d_kernel(ConvParams p) {
-  constexpr int RPT = 32 / QW;                 // patch rows of UNITS per 32-unit MFMA tile (unit = 2 rows x 4 pixels)
-  static_assert(QW == 8 || QW == 16, "quads per patch row");
-  static_assert(TH == 2 * RPT, "one 32-unit MFMA row tile per workgroup: TH = 2 * 32 / QW");
-  constexpr int NG = BN / 32, NW = 4 * NG, NT = NW * 64;
-  constexpr int HR = TH + 2;
-  constexpr int A_PLANE = QW * 8;              // floats of one nu plane of a halo row
-  constexpr int A_STAGE = HR * 6 * A_PLANE;    // floats: [hy][nu][quad][8]
-  constexpr int ITEMS = HR * QW * 2;           // (halo row, quad, 4-channel group)
-  constexpr int PXW = 4 * QW;
-  static_assert(ITEMS <= NT, "staging items");
+  constexpr int QW = 8, TH = 8, HR = TH + 2, PXW = 4 * QW, PW = PXW + 2;
+  constexpr int NG = BN / 32, NW = 4 * NG;
+  constexpr int RP4 = 148, MO4 = 36, CO4 = 9;   // row pitch, m stride, piece stride in 16-byte slots (2368, 576, 144 bytes)
+  constexpr int NREQ = 24;                      // DMA requests (1 KB each) per stage: 10 rows x 148 slots = 1480 <= 1536
+  constexpr int STAGE4 = NREQ * 64;             // slots per stage
+  constexpr int NS = 3;                         // stages
+  constexpr int IPW = NREQ / NW;                // requests per wave and super-chunk
+  static_assert(NREQ % NW == 0, "requests per wave");
+  static_assert(HR * RP4 <= STAGE4, "stage size");
+  constexpr bool XF = (FLAGS & W2D_F_XFIRST) != 0;
   constexpr unsigned OOB = 0xFFFFFFFFu;
-  constexpr bool RAW = (FLAGS & W2D_F_RAW) != 0;
-  constexpr bool MID = (FLAGS & W2D_F_MIDBAR) != 0;
-  constexpr int NST = MID ? 3 : 2;             // activation stages
-  static_assert(!MID || ((FLAGS & W2D_F_ILV) && (FLAGS & W2D_F_B2)), "W2D_F_MIDBAR needs W2D_F_ILV and W2D_F_B2");
-  constexpr int PW = PXW + 2;                  // halo pixels per patch row
-  constexpr int NPIX = HR * PW;
-  constexpr int NI = (NPIX + 15) / 16;         // raw requests (16 pixels x 64 B = 1 KB of LDS each) per 16-channel super-chunk
-  constexpr int IPW = (NI + NW - 1) / NW;      // per wave
-  constexpr int R_STAGE = IPW * NW * 256;      // floats of one raw buffer (every wave issues IPW requests; those past NI write
-                                               // zeros behind the patch); LDS: [A0][A1][R0][R1]
-  static_assert(!RAW || QW == 8, "raw staging: 8-quad patch rows");
 
-  extern __shared__ __attribute__((aligned(1024))) float smem[];  // [A0][A1]; the epilogue reuses it as the exchange buffer
+  extern __shared__ __attribute__((aligned(1024))) float smem[];  // [stage 0][stage 1][stage 2]; the epilogue reuses it as the exchange buffer
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int mu = wv & 3, ng = wv >> 2;
+
+  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm0 = __builtin_readcyclecounter();
 
   int bx = blockIdx.x, by = blockIdx.y;
   if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
@@ -98,186 +98,61 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     bx = nl / nby;
     by = nl - bx * nby;
   }
-  if constexpr ((FLAGS & (W2D_F_GRP256 | W2D_F_GRP128 | W2D_F_GRP512)) != 0) {
-    constexpr int G = (FLAGS & W2D_F_GRP256) ? 256 : (FLAGS & W2D_F_GRP128) ? 128 : 512;
-    const int nbx = gridDim.x, nby = gridDim.y;
-    const int lin = by * nbx + bx;
-    const int g = lin / (G * nby), r = lin - g * (G * nby);
-    const int gl = nbx - g * G < G ? nbx - g * G : G;
-    by = r / gl;
-    bx = g * G + (r - by * gl);
-  }
   const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
   const int img = bx / (ntx * nty);
   const int trem = bx - img * (ntx * nty);
   const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * PXW;
   const int n0 = by * BN;
 
-  // ---- A staging: conv_wino43_kernel's item (halo row hy, quad tq, channel group q) on the first ITEMS threads ------------
-  const bool stager = t < ITEMS;
-  const int f = stager ? t : 0;
-  const int aq = f & 1, tq = (f >> 1) % QW, ahy = (f >> 1) / QW;
-  const int a_y = y0 - 1 + ahy, a_x = x0 - 1 + 4 * tq;
-  unsigned a_ok = 0;
-  if (stager && a_y >= 0 && a_y < p.H)
-    for (int j = 0; j < 6; ++j)
-      if (a_x + j >= 0 && a_x + j < p.W) a_ok |= 1u << j;
-  // K-half swap so that a 16-lane fragment read covers all 64 banks once: QW >= 16 on bit 3 of the quad; QW = 8 (16 lanes = two
-  // unit rows, i.e. halo rows TWO apart) on bit 1 of the halo row (bit 0 would give both rows the same half: measured as 35 %
-  // of the LDS cycles in bank conflicts, profiles/r03_pmc_conv_bench_w2d.md)
-  const int a_lds = ((ahy * 6) * QW + tq) * 8 + ((aq ^ (QW >= 16 ? ((tq >> 3) & 1) : ((ahy >> 1) & 1))) << 2);
-  const int scol = aq * 4;
-  unsigned a_off = 0, a_pix = 0;
-  unsigned pfo[2] = {OOB, OOB};   // W2D_F_PFA: the pixel this thread touches ahead on even / odd chunks (pixels 1..4 of the quad between
-                                  // the two channel-group threads and the two chunk parities: every pixel of the row once per two chunks)
-  unsigned aoffj[6];   // byte offsets of the item's six pixels (out of range where the pixel is outside the image): fixed per
-                       // segment, so that a chunk's loads need no address arithmetic and the registers stay theirs
-  conv_rsrc_t arsrc = conv_make_rsrc(p.seg[0].ptr);
-  int sg = 0, c0 = 0, segC = p.seg[0].C;
-  auto setup_seg = [&]() {
-    const ConvSeg& s = p.seg[sg];
-    segC = s.C;
-    a_pix = (unsigned)s.stride * 4u;
-    int be = img + s.boff;
-    if (s.bmod && be >= s.bmod) be -= s.bmod;
-    arsrc = conv_make_rsrc(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride);
-    a_off = (unsigned)((ahy * p.W + a_x) * s.stride + scol) * 4u;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      aoffj[j] = ((a_ok >> j) & 1u) ? a_off + (unsigned)j * a_pix : OOB;
-      if constexpr ((FLAGS & W2D_DBG_AHOT) != 0) aoffj[j] = ((a_ok >> j) & 1u) ? (aoffj[j] & 0xFFF0u) + (unsigned)(p.W * s.stride) * 4u : OOB;
-      asm volatile("" : "+v"(aoffj[j]));   // keep it in its register (hipcc otherwise recomputes it per chunk into registers that
-                                           // are still the destination of loads in flight, and has to wait for those)
-    }
-    if constexpr ((FLAGS & W2D_F_PFA) != 0) {
-      pfo[0] = aq ? aoffj[3] : aoffj[1];
-      pfo[1] = aq ? aoffj[4] : aoffj[2];
-      asm volatile("" : "+v"(pfo[0]));
-      asm volatile("" : "+v"(pfo[1]));
-    }
-  };
-  const int nkc = p.Ctot / 8;
-  bf4 araw[2][6];
-  bool chunk_ok = true;
-  auto load_item = [&](auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    const unsigned so = (FLAGS & W2D_DBG_AHOT) ? ((unsigned)c0 * 4u) & 96u : (unsigned)c0 * 4u;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) araw[SET][j] = conv_buf_load(arsrc, aoffj[j], so);
-  };
-  auto store_item = [&](int stage, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    float* As = smem + stage * A_STAGE + a_lds;
-    bf4 v[6];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float d0 = araw[SET][0][c], d1 = araw[SET][1][c], d2 = araw[SET][2][c], d3 = araw[SET][3][c], d4 = araw[SET][4][c], d5 = araw[SET][5][c];
-      const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
-      const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
-      v[0][c] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-      v[1][c] = t1 + t2;
-      v[2][c] = t1 - t2;
-      v[3][c] = t3 + t4;
-      v[4][c] = t3 - t4;
-      v[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-    }
-#pragma unroll
-    for (int nu = 0; nu < 6; ++nu) *reinterpret_cast<bf4*>(As + nu * A_PLANE) = v[nu];
-  };
-  auto next_chunk = [&](int kc_next) {
-    if (kc_next >= nkc) {   // past the last chunk: the remaining (prefetch) loads read nothing
-      chunk_ok = false;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) aoffj[j] = OOB;
-      pfo[0] = pfo[1] = OOB;
-      return;
-    }
-    c0 += 8;
-    if (c0 >= segC) { c0 = 0; ++sg; setup_seg(); }
-  };
-
-  // ---- W2D_F_RAW: raw halo patch in LDS.  Request i of a super-chunk covers linear halo pixels P = 16 i .. 16 i + 15 (P = halo
-  // row * PW + pixel), lane l -> LDS slot l of the request's 1 KB (that is how `buffer_load ... lds` places the lanes).  The
-  // slot <-> (pixel q = P & 15, 16-B piece c = 2 h + a) map is chosen for the READ side: the 16 lanes of a ds_read_b128
-  // group are the items (a, quad 0..7) of one halo row = pixels FOUR apart, same h; slot = (q & 3) * 16 + (h ^ (i & 1)) * 8 +
-  // (q >> 2) * 2 + a gives them 16 different slots mod 16 (all 64 banks once).
+  // ---- DMA side: request n of this wave fills slots 64 * (wv + NW n) ... + 63 of a stage; lane -> (halo row, pixel, piece) -----
   unsigned rvoff[IPW];
   int rsg = 0, rc0 = 0, rsegC = 0;
   conv_rsrc_t rrsrc = conv_make_rsrc(p.seg[0].ptr);
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-  unsigned rbad = 0;   // bit n: request n of this lane is outside the image (or past the patch)
-  auto raw_pixel = [&](int n, int& pc) {   // this lane's (pixel of the patch row block, piece) of its wave's n-th request
-    const int i = wv + NW * n;
-    const int q = ((lane >> 1) & 3) * 4 + (lane >> 4), h = ((lane >> 3) & 1) ^ (i & 1);
-    pc = 2 * h + (lane & 1);
-    return 16 * i + q;
-  };
-  if constexpr (RAW) {
-#pragma unroll
-    for (int n = 0; n < IPW; ++n) {
-      int pc;
-      const int P = raw_pixel(n, pc), hy = P / PW, px = P - hy * PW;
-      const int y = y0 - 1 + hy, x = x0 - 1 + px;
-      if (!(P < NPIX && y >= 0 && y < p.H && x >= 0 && x < p.W)) rbad |= 1u << n;
-    }
-  }
-  auto raw_setup_seg = [&]() {
+  auto raw_setup_seg = [&]() {   // (once per input segment: the lane's slots are re-derived here rather than kept in registers)
     const ConvSeg& s = p.seg[rsg];
     rsegC = s.C;
     int be = img + s.boff;
     if (s.bmod && be >= s.bmod) be -= s.bmod;
     rrsrc = conv_make_rsrc(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // opaque: keeps the slot arithmetic below out of the K loop's live registers
 #pragma unroll
     for (int n = 0; n < IPW; ++n) {
-      int pc;
-      const int P = raw_pixel(n, pc), hy = P / PW, px = P - hy * PW;
-      rvoff[n] = ((unsigned)((hy * p.W + (x0 - 1 + px)) * s.stride + pc * 4) * 4u) | (0u - ((rbad >> n) & 1u));
+      const int sl = 64 * (wv + NW * n) + ln;
+      const int r = sl / RP4, rem = sl - r * RP4;
+      const int m = rem / MO4, rr = rem - m * MO4;
+      const int c = rr / CO4, k = rr - c * CO4;
+      const int px = 4 * k + m;
+      const int y = y0 - 1 + r, x = x0 - 1 + px;
+      const bool ok = r < HR && rem < 4 * MO4 && px < PW && y >= 0 && y < p.H && x >= 0 && x < p.W;   // else padding / outside the image
+      rvoff[n] = ok ? (unsigned)((r * p.W + x) * s.stride + c * 4) * 4u : OOB;
       asm volatile("" : "+v"(rvoff[n]));
     }
   };
-  auto raw_issue = [&](int buf) {   // the next super-chunk (16 channels) of the patch -> raw buffer `buf`; advances the raw cursor
+  auto dma_piece = [&](int n, int stage) {   // request n of this wave's share of the cursor's super-chunk -> stage
     const unsigned so = (unsigned)rc0 * 4u;
-    const unsigned base = lds0 + (unsigned)(NST * A_STAGE + buf * R_STAGE) * 4u + (unsigned)wv * 1024u;
-#pragma unroll
-    for (int n = 0; n < IPW; ++n)
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(base + (unsigned)(NW * n) * 1024u), "v"(rvoff[n]), "s"(rrsrc), "s"(so)
-                   : "memory");   // (m0 is reserved in the AMDGPU backend: the compiler writes it right at each of its own uses and
-                                  // never keeps a value there across other code, so it is not - and cannot be - listed as a clobber)
+    const unsigned base = lds0 + (unsigned)stage * (STAGE4 * 16u) + (unsigned)(wv + NW * n) * 1024u;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(base), "v"(rvoff[n]), "s"(rrsrc), "s"(so)
+                 : "memory");   // (m0 is written in the statement that reads it: the compiler never keeps a value there across other code)
+  };
+  auto dma_advance = [&]() {   // the cursor moves to the next super-chunk (16 channels), into the next input segment behind the last one
     rc0 += 16;
     if (rc0 >= rsegC && rsg + 1 < p.nseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
   };
-  // read side: float4 index (within a raw buffer) of pixel j of this thread's item, piece a = aq, for h = 0 (h = 1: ^ 8)
-  unsigned xj[6];
-  if constexpr (RAW) {
+  auto raw_issue = [&](int stage) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int P = ahy * PW + 4 * tq + j, i = P >> 4, q = P & 15;
-      xj[j] = (unsigned)(i * 64 + (((q & 3) * 16 + (q >> 2) * 2 + aq) | ((i & 1) << 3)));
-    }
-  }
-  const bf4* const smem4r = reinterpret_cast<const bf4*>(smem);
-  auto raw_read = [&](bf4 (&rv)[6], int buf, int h) {
-    const unsigned b4 = (unsigned)(NST * A_STAGE + buf * R_STAGE) / 4u, hx = (unsigned)h << 3;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      asm volatile("" : "+v"(xj[j]));   // opaque: otherwise the four (buffer, h) address sets are hoisted out of the K loop (24 registers)
-      rv[j] = smem4r[b4 + (xj[j] ^ hx)];
-    }
+    for (int n = 0; n < IPW; ++n) dma_piece(n, stage);
+    dma_advance();
   };
 
   // ---- weights: [Cout / 32][chunk][mu][nu][K half][32][4] floats; this wave reads slab (ct, kc, mu): 6 x 1 KB -----------------
+  const int nkc = p.Ctot / 8, nsc = nkc / 2;
   const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const int ct = n0 / 32 + ng;
+  auto slab = [&](int kc) { return (unsigned)(((ct * nkc + (kc < nkc ? kc : nkc - 1)) * 4 + mu) * 6) * 1024u; };
   bf4 fbg[2][6];
-  float pfa[2] = {0.f, 0.f}, pfb[2] = {0.f, 0.f};   // touch-ahead destinations (never read; kept live until the load has landed)
-  const unsigned pfb_off = lane < 48 ? (unsigned)lane * 128u : OOB;
-  auto load_b = [&](int kc, auto set_c) {
-    constexpr int SET = decltype(set_c)::value;
-    const unsigned so = (unsigned)(((ct * nkc + (kc < nkc ? kc : nkc - 1)) * 4 + mu) * 6) * 1024u;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) fbg[SET][j] = conv_buf_load(brsrc, bvoff, so + (unsigned)j * 1024u);   // one address register for the six loads
-  };
 
   f32x16 acc[6];
 #pragma unroll
@@ -285,242 +160,290 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
 
-  // ---- A fragments: lane (unit row ur, quad lq, K half) reads halo rows 2 ur + ra and 2 ur + rb and combines them ----------
-  //   mu 0: v[0] - v[2]   mu 1: v[1] + v[2]   mu 2: v[2] - v[1]   mu 3: v[1] - v[3]
+  // ---- fragments: lane (unit row ur, quad lq, K half) reads pixels 4 lq .. 4 lq + 5 of halo rows 2 ur + ra and 2 ur + rb --------
   const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
-  constexpr int A_STAGE4 = A_STAGE / 4;
-  const int ur = l31 / QW, lq = l31 % QW;
+  const int ur = l31 >> 3, lq = l31 & 7;
   const int ra = mu == 0 ? 0 : mu == 2 ? 2 : 1, rb = mu == 0 ? 2 : mu == 1 ? 2 : mu == 2 ? 1 : 3;
   const float sgn = mu == 1 ? 1.f : -1.f;
-  auto row_ad = [&](int hy) {   // float4 index of (halo row hy, nu 0, quad lq, this lane's K half)
-    const int sw = QW >= 16 ? ((lq >> 3) & 1) : ((hy >> 1) & 1);
-    return ((hy * 6) * QW + lq) * 2 + (half ^ sw);
-  };
-  const int ad_a = row_ad(2 * ur + ra), ad_b = row_ad(2 * ur + rb);
+  const int ix_a = (2 * ur + ra) * RP4 + half * CO4 + lq, ix_b = (2 * ur + rb) * RP4 + half * CO4 + lq;
+  float A[2][6][4];   // A[kc & 1]: the fragments of chunk kc (all six nu planes, this lane's four channels)
+  bf4 d[6];           // raw pixels of row a (then: of the combined row)
+  bf4 d2[6];          // raw pixels of row b
 
   using C0 = std::integral_constant<int, 0>;
   using C1 = std::integral_constant<int, 1>;
-  // Every thread issues the activation loads - threads without an item have a_ok = 0, i.e. out-of-range offsets that
-  // return zero without touching memory - so that all waves have the SAME number of loads in flight: with the loads under
-  // `if (stager)` the compiler has to place one s_waitcnt vmcnt(n) valid for both paths, and the staging waves then wait
-  // for the weight loads they issued a moment ago (a full L2 latency per chunk)
-  bf4 fa[2], fb2[2];   // A fragments (two halo rows) of the current / next nu step
-  int st_cur = 0;      // activation stage of the current chunk
-  const int nsc = nkc / 2;   // W2D_F_RAW: super-chunks
-  if constexpr (RAW) {
-    raw_setup_seg();
-    raw_issue(0);
-    if (nsc > 1) raw_issue(1);
-    load_b(0, C0{});
-    if constexpr ((FLAGS & W2D_F_B2) != 0) load_b(1, C1{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (stager) {
-      raw_read(araw[0], 0, 0);
-      store_item(0, C0{});
-    }
-    __syncthreads();
-  } else {
-    setup_seg();
-    load_item(C0{});
-    load_b(0, C0{});
-    if constexpr ((FLAGS & W2D_F_B2) != 0) load_b(1, C1{});
-    // (the chunk / segment state - c0, the buffer resource - advances on EVERY thread: kept uniform it lives in scalar
-    // registers; advanced under `if (stager)` it becomes a per-lane value and every buffer load turns into a waterfall loop)
-    next_chunk(1);
-    load_item(C1{});
-    if (stager) store_item(0, C0{});
-    next_chunk(2);
-    __syncthreads();
-  }
-  if constexpr (MID) {   // step 0 of chunk 0
-    fa[0] = reinterpret_cast<const bf4*>(smem)[ad_a];
-    fb2[0] = reinterpret_cast<const bf4*>(smem)[ad_b];
-  }
-
-  auto chunk = [&](int kc, auto par_c) {
-    constexpr int PAR = decltype(par_c)::value;
-    const int st_next = st_cur + 1 == NST ? 0 : st_cur + 1;
-    const int sa = st_cur * A_STAGE4;
-    if constexpr (RAW && PAR == 1 && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOALD)) == 0) {   // odd chunk: raw buffer (kc >> 1) & 1 was last read in chunk kc - 1; refill it with super-chunk
-                                       // (kc >> 1) + 2.  Issued BEFORE the weight requests: the compiler's vmcnt counts for those stay
-                                       // exact, and the wait for the last weight slab of chunk kc + 1 covers these (in-order return),
-                                       // so the barrier that ends chunk kc + 1 publishes the buffer - first read in chunk kc + 2
-      if ((kc >> 1) + 2 < nsc) raw_issue((kc >> 1) & 1);
-    }
-    constexpr bool B2 = (FLAGS & W2D_F_B2) != 0;
-    if constexpr ((FLAGS & W2D_DBG_NOB) == 0 && !B2) load_b(kc + 1, std::integral_constant<int, 1 - PAR>{});
-    const unsigned so2 = (unsigned)(((ct * nkc + (kc + 2 < nkc ? kc + 2 : nkc - 1)) * 4 + mu) * 6) * 1024u;   // B2: slab (kc + 2)
-    if constexpr (!RAW && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOALD)) == 0) load_item(par_c);   // chunk kc + 2 into the register set chunk kc came from
-    if constexpr ((FLAGS & W2D_F_PFA) != 0) {   // after the real loads: in-order completion then gives the touch two chunk times
-      asm volatile("" ::"v"(pfa[PAR]));
-      pfa[PAR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(arsrc, (int)pfo[PAR], (int)((unsigned)c0 * 4u + 128u), 0));
-    }
-    if constexpr ((FLAGS & W2D_F_PFB) != 0) {
-      asm volatile("" ::"v"(pfb[PAR]));
-      const unsigned so3 = (unsigned)(((ct * nkc + (kc + 3 < nkc ? kc + 3 : nkc - 1)) * 4 + mu) * 6) * 1024u;
-      pfb[PAR] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(brsrc, (int)pfb_off, (int)so3, 0));
-    }
-    __builtin_amdgcn_sched_barrier(0);   // the twelve requests of the chunk go out first, in this order (the s_waitcnt counts below rely on it)
-    bf4 sv[6];   // W2D_F_ILV: the item of chunk kc + 1, transformed two channels per nu step
-    constexpr bool ILV = (FLAGS & W2D_F_ILV) != 0 && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0;
-    auto xform = [&](int c) {
-      constexpr int SET = 1 - PAR;
-      const float d0 = araw[SET][0][c], d1 = araw[SET][1][c], d2 = araw[SET][2][c], d3 = araw[SET][3][c], d4 = araw[SET][4][c], d5 = araw[SET][5][c];
-      const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
-      const float t3 = d4 - d2, t4 = 2.f * (d3 - d1);
-      sv[0][c] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
-      sv[1][c] = t1 + t2;
-      sv[2][c] = t1 - t2;
-      sv[3][c] = t3 + t4;
-      sv[4][c] = t3 - t4;
-      sv[5][c] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
-    };
-    float* const As_next = smem + st_next * A_STAGE + a_lds;
-    constexpr bool COMB = (FLAGS & W2D_DBG_NOCOMB) == 0;
-    if constexpr (!MID) {
-      fa[0] = smem4[sa + ad_a];
-      if constexpr (COMB) fb2[0] = smem4[sa + ad_b];
-    }
+  auto read_row = [&](bf4 (&dst)[6], int ix, int stage, auto h_c) {
+    constexpr int IMM = decltype(h_c)::value * 2 * CO4;
+    const int ixs = ix + stage * STAGE4;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      if (j + 1 < 6) {
-        fa[(j + 1) & 1] = smem4[sa + ad_a + (j + 1) * (QW * 2)];
-        if constexpr (COMB) fb2[(j + 1) & 1] = smem4[sa + ad_b + (j + 1) * (QW * 2)];
-      } else if constexpr (MID) {   // step 0 of the next chunk: its stage was published by the barrier behind step 3
-        fa[0] = smem4[st_next * A_STAGE4 + ad_a];
-        if constexpr (COMB) fb2[0] = smem4[st_next * A_STAGE4 + ad_b];
-      }
-      bf4 a;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) a[k] = COMB ? __builtin_fmaf(sgn, fb2[j & 1][k], fa[j & 1][k]) : fa[j & 1][k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k], fbg[PAR][j][k], acc[j], 0, 0, 0);
-      if constexpr (B2 && (FLAGS & W2D_DBG_NOB) == 0) fbg[PAR][j] = conv_buf_load(brsrc, bvoff, so2 + (unsigned)j * 1024u);
-      if constexpr ((FLAGS & W2D_DBG_NOAST) != 0) {
-        if (j == ((FLAGS & W2D_F_LATE) ? 2 : 0)) {
-#pragma unroll
-          for (int q = 0; q < 6; ++q)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(araw[1 - PAR][q][c]));
-        }
-      }
-      if constexpr (RAW && ILV) {
-        if (j == 0 && stager) raw_read(araw[1 - PAR], ((kc + 1) >> 1) & 1, 1 - PAR);   // the item of chunk kc + 1: h = (kc + 1) & 1
-      }
-      if constexpr (ILV) {
-        if (stager) {
-          constexpr int J0 = (FLAGS & W2D_F_LATE) ? 2 : 0;
-          // transform steps / store steps: behind the raw read of step 0 (RAW) and in front of the barrier behind step 3 (MID)
-          constexpr int JX0 = MID ? (RAW ? 1 : 0) : J0, JX1 = JX0 + 1, JS0 = MID ? 2 : J0 + 2, JS1 = JS0 + 1;
-          if (j == JX0) { xform(0); xform(1); }
-          if (j == JX1) { xform(2); xform(3); }
-          if (j == JS0) {
-#pragma unroll
-            for (int nu = 0; nu < 3; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
-          }
-          if (j == JS1) {
-#pragma unroll
-            for (int nu = 3; nu < 6; ++nu) *reinterpret_cast<bf4*>(As_next + nu * A_PLANE) = sv[nu];
-          }
-        }
-      }
-      if constexpr (MID) {
-        if (j == 3) {
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (RAW && PAR == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // the raw requests of chunk kc - 1 (ten weight requests younger)
-          __syncthreads();
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (!ILV && (FLAGS & (W2D_DBG_NOA | W2D_DBG_NOAST)) == 0) { if (stager) store_item((kc + 1) & 1, std::integral_constant<int, 1 - PAR>{}); }   // chunk kc + 1
-    if constexpr (RAW && B2 && PAR == 0 && !MID)   // the raw requests of chunk kc - 1 are older than the last 12 weight requests (in-order return):
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // landed before the barrier publishes them (also waits for the next chunk's slabs)
-    if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0 && !MID) __syncthreads();
-    if constexpr (!RAW) next_chunk(kc + 3);
-    st_cur = st_next;
+    for (int j = 0; j < 6; ++j) dst[j] = smem4[ixs + IMM + (j & 3) * MO4 + (j >> 2)];
   };
-  // pairs without a condition between the two chunks (with `if (kc + 1 < nkc)` inside the loop the compiler has to size every
-  // s_waitcnt for the path on which the odd chunk's requests were never issued - six fewer in flight, half the lookahead gone)
-  int kc = 0;
-  for (; kc + 1 < nkc; kc += 2) {
+  // F(4,3) B^T of channel c of the six pixels in d: 12 operations (v3 / v4 = t3 +- 2 (d3 - d1): the doubling is exact, so
+  // fma(+-2, d3 - d1, t3) rounds the very sum conv_wino2d_r3_kernel formed with a multiplication and an addition)
+  float xt[4];
+  auto xf_t = [&](int c) {
+    const float d1 = d[1][c], d2v = d[2][c], d3 = d[3][c], d4 = d[4][c];
+    xt[0] = __builtin_fmaf(-4.f, d2v, d4);
+    xt[1] = __builtin_fmaf(-4.f, d1, d3);
+    xt[2] = d4 - d2v;
+    xt[3] = d3 - d1;
+  };
+  auto xf_v = [&](int c, int nu) -> float {
+    if constexpr ((FLAGS & W2D_DBG_NOXF) != 0) return d[nu][c];
+    switch (nu) {
+      case 0: return __builtin_fmaf(4.f, d[0][c], __builtin_fmaf(-5.f, d[2][c], d[4][c]));
+      case 1: return xt[0] + xt[1];
+      case 2: return xt[0] - xt[1];
+      case 3: return __builtin_fmaf(2.f, xt[3], xt[2]);
+      case 4: return __builtin_fmaf(-2.f, xt[3], xt[2]);
+      default: return __builtin_fmaf(4.f, d[1][c], __builtin_fmaf(-5.f, d[3][c], d[5][c]));
+    }
+  };
+  // hipcc sinks a value whose only readers sit behind the next branch (the next chunk) out of the MFMA gap it was written in -
+  // down to one block of VALU instructions in front of the chunk that needs them: an empty statement "using" it pins it
+  auto pin = [](float& v) { asm volatile("" : "+v"(v)); };
+  // the whole preparation of a chunk's fragments in one go (prologue only)
+  auto prepare = [&](float (&An)[6][4], int stage, auto h_c) {
+    read_row(d, ix_a, stage, h_c);
+    read_row(d2, ix_b, stage, h_c);
+    if constexpr (!XF) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) d[j][c] = __builtin_fmaf(sgn, d2[j][c], d[j][c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      xf_t(c);
+#pragma unroll
+      for (int nu = 0; nu < 6; ++nu) An[nu][c] = xf_v(c, nu);
+    }
+    if constexpr (XF) {
+#pragma unroll
+      for (int j = 0; j < 6; ++j) d[j] = d2[j];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        xf_t(c);
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) An[nu][c] = __builtin_fmaf(sgn, xf_v(c, nu), An[nu][c]);
+      }
+    }
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------------------
+  raw_setup_seg();
+  raw_issue(0);
+#pragma unroll
+  for (int set = 0; set < 2; ++set)
+#pragma unroll
+    for (int j = 0; j < 6; ++j) fbg[set][j] = conv_buf_load(brsrc, bvoff, slab(set) + (unsigned)j * 1024u);
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // this wave's share of stage 0 (older than the twelve weight requests)
+  __syncthreads();
+  if (nsc > 1) raw_issue(1);
+  if (nsc > 2) raw_issue(2);
+  prepare(A[0], 0, C0{});
+
+  // ---- K loop: chunk kc = (super-chunk s, half h).  Super-chunk s lives in stage s % 3; chunk kc prepares the fragments of chunk
+  // kc + 1 while its own MFMAs run.  The barrier at the top of chunk (s, 1) publishes super-chunk s + 1 (first read right behind it)
+  // and says that nobody reads stage s % 3 any more: super-chunk s + 3 goes there, its requests in gaps of chunks (s, 1), (s + 1, 0).
+  int st_s = 0, st_n = 1;    // stages of super-chunks s and s + 1
+  int st_dma = 0;            // stage of the super-chunk whose requests are being issued
+  bool dma_on = false;
+  constexpr int P1 = (IPW + 1) / 2, P0 = IPW - P1;   // requests issued in the gaps of chunk (s, 1) / of chunk (s + 1, 0)
+  static_assert(P0 > 0, "the cursor advances behind the last request of chunk (s + 1, 0)");
+  auto chunk = [&](int kc, auto h_c) {
+    constexpr int H = decltype(h_c)::value;
+    using RH = std::integral_constant<int, 1 - H>;
+    const int rs = H == 0 ? st_s : st_n;   // stage of chunk kc + 1
+    float(&Ac)[6][4] = A[H];
+    float(&An)[6][4] = A[1 - H];
+    if constexpr (H == 1) {
+      // This wave's requests for super-chunk s + 1 are older than the weight requests of the last chunks (in-order return): the last
+      // one went out in a gap of chunk kc - 3, at least 14 weight requests ago (s + 1 < 3: in the prologue, behind it DMA requests
+      // and the 6 weight requests of chunk 0).  Everybody else's are published by the barrier.
+      if constexpr ((FLAGS & W2D_DBG_NOB) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else {
+        if (kc == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+      }
+      if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
+      dma_on = (kc >> 1) + NS < nsc;
+      st_dma = st_s;
+    }
+    const unsigned so2 = slab(kc + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    auto gap = [&](auto g_c) {
+      constexpr int g = decltype(g_c)::value;
+      constexpr int jp = g >> 3, i8 = g & 7, k = i8 >> 1, j = 2 * jp + (i8 & 1);
+      // A = weights (row = output channel), B = activations (column = unit): C^T of conv_wino2d_r3_kernel's tile, the same k-ordered sums
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k], acc[j], 0, 0, 0);
+      if constexpr ((FLAGS & W2D_DBG_NOB) == 0) {
+        if constexpr (k == 3) fbg[H][j] = conv_buf_load(brsrc, bvoff, so2 + (unsigned)j * 1024u);   // consumed: chunk kc + 2's slab into the same registers
+      }
+      if constexpr ((FLAGS & W2D_DBG_NORD) == 0) {
+        if constexpr (g == 0) read_row(d, ix_a, rs, RH{});
+        if constexpr (!XF && g == 1) read_row(d2, ix_b, rs, RH{});
+        if constexpr (XF && g == 10) read_row(d, ix_b, rs, RH{});
+      }
+      if constexpr (!XF) {
+        if constexpr (g >= 4 && g < 10) {   // y combine of pixel g - 4
+          constexpr int jj = g - 4;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { float v = __builtin_fmaf(sgn, d2[jj][c], d[jj][c]); pin(v); d[jj][c] = v; }
+        }
+        if constexpr (g >= 10 && g < 22) {   // x transform: channel (g - 10) / 3 in three parts
+          constexpr int c = (g - 10) / 3, part = (g - 10) % 3;
+          if constexpr (part == 0) {
+            xf_t(c);
+            An[0][c] = xf_v(c, 0);
+            An[5][c] = xf_v(c, 5);
+            pin(An[0][c]); pin(An[5][c]); pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+          } else if constexpr (part == 1) {
+            An[1][c] = xf_v(c, 1);
+            An[2][c] = xf_v(c, 2);
+            pin(An[1][c]); pin(An[2][c]);
+          } else {
+            An[3][c] = xf_v(c, 3);
+            An[4][c] = xf_v(c, 4);
+            pin(An[3][c]); pin(An[4][c]);
+          }
+        }
+      } else {
+        if constexpr (g >= 2 && g < 10) {          // row a: channel (g - 2) / 2, first / second half of its operations
+          constexpr int c = (g - 2) >> 1;
+          if constexpr (((g - 2) & 1) == 0) {
+            xf_t(c);
+            An[0][c] = xf_v(c, 0);
+            An[5][c] = xf_v(c, 5);
+            pin(An[0][c]); pin(An[5][c]); pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+          } else {
+#pragma unroll
+            for (int nu = 1; nu < 5; ++nu) { An[nu][c] = xf_v(c, nu); pin(An[nu][c]); }
+          }
+        }
+        if constexpr (g >= 12) {                   // row b + y combine: channel (g - 12) / 3 in three parts
+          constexpr int c = (g - 12) / 3, part = (g - 12) % 3;
+          if constexpr (part == 0) {
+            xf_t(c);
+            An[0][c] = __builtin_fmaf(sgn, xf_v(c, 0), An[0][c]);
+            An[5][c] = __builtin_fmaf(sgn, xf_v(c, 5), An[5][c]);
+            pin(An[0][c]); pin(An[5][c]); pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+          } else if constexpr (part == 1) {
+            An[1][c] = __builtin_fmaf(sgn, xf_v(c, 1), An[1][c]);
+            An[2][c] = __builtin_fmaf(sgn, xf_v(c, 2), An[2][c]);
+            pin(An[1][c]); pin(An[2][c]);
+          } else {
+            An[3][c] = __builtin_fmaf(sgn, xf_v(c, 3), An[3][c]);
+            An[4][c] = __builtin_fmaf(sgn, xf_v(c, 4), An[4][c]);
+            pin(An[3][c]); pin(An[4][c]);
+          }
+        }
+      }
+      if constexpr ((FLAGS & W2D_DBG_NODMA) == 0) {   // a DMA request in a gap without fragment reads
+        constexpr int CNT = H == 1 ? P1 : P0, N0 = H == 1 ? 0 : P1;
+        constexpr int step = 24 / CNT;
+        if constexpr (g % step == (CNT == 1 ? 13 : 5) && g / step < CNT) {
+          if (dma_on) {
+            dma_piece(N0 + g / step, st_dma);
+            if constexpr (H == 0 && g / step == CNT - 1) dma_advance();
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    w2d_for_each(gap, std::make_integer_sequence<int, 24>{});
+    if constexpr (H == 1) {
+      st_s = st_n;
+      st_n = st_n + 1 == NS ? 0 : st_n + 1;
+    }
+  };
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm1 = __builtin_readcyclecounter();
+  for (int kc = 0; kc < nkc; kc += 2) {
     chunk(kc, C0{});
     chunk(kc + 1, C1{});
   }
-  if constexpr (!RAW) {
-    if (kc < nkc) chunk(kc, C0{});
-  }
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm2 = __builtin_readcyclecounter();
 
-  // ---- epilogue: x inverse in registers (conv_wino43's y0..y3 per mu), then the y inverse across the four mu waves of a
-  // channel tile through LDS, one x position per round: waves mu = 1, 2 publish, mu = 0 forms row 2k = (m0 + m1) + m2,
-  // mu = 3 forms row 2k + 1 = (m1 - m2) - m3.  C/D layout of the 32x32 MFMA: col = lane & 31 (cout), row = (r&3) + 8*(r>>2)
-  // + 4*(lane>>5) = unit.
-  if constexpr (MID) __syncthreads();   // no barrier behind the last chunk's steps 4 / 5 (fragment reads): the exchange buffer overlays the stages
-  float* const xbuf = smem;                                  // [ng][which: mu 1 / mu 2][16 regs][64 lanes]
-  const int n = n0 + ng * 32 + l31;
-  const float bv = p.bias[n];
+  // ---- epilogue.  C/D layout of the 32x32 MFMA with A = weights: column = lane & 31 = unit, row = (r&3) + 8*(r>>2) + 4*(lane>>5) =
+  // output channel of the wave's 32.  x inverse in registers (per mu plane; conv_wino2d_r3_kernel's sums: the products by 2, 4, 8 are
+  // exact, so the fused forms round the same values), then per x position jx one round: every wave writes its plane
+  // [unit][32 channels] (16-byte pieces swizzled by the unit: conflict-free both ways), barrier, thread (unit, 4-channel group)
+  // reads the four mu planes and forms row 2k = (m0 + m1) + m2 and row 2k + 1 = (m1 - m2) - m3 (conv_wino2d_r3_kernel's), bias,
+  // leaky_relu, two dwordx4 stores.  Two exchange buffers: the writes of round jx + 1 do not wait for the readers of round jx.
+  __syncthreads();   // the exchange buffers overlay the stages (the last chunk prepared fragments nobody uses: its reads are done)
+  float o[4][16];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    float o[16];
+  for (int r = 0; r < 16; ++r) {
+    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+    const float s34 = m3 + m4, d34 = m3 - m4, d12 = m1 - m2, s12 = m1 + m2;
+    o[0][r] = ((m0 + m1) + m2) + s34;
+    o[1][r] = __builtin_fmaf(2.f, d34, d12);
+    o[2][r] = __builtin_fmaf(4.f, s34, s12);
+    o[3][r] = d12 + __builtin_fmaf(8.f, d34, m5);
+  }
+  bf4* const xb = reinterpret_cast<bf4*>(smem);   // [buffer 2][ng][mu][unit 32][piece 8] float4
+  constexpr int XB4 = NG * 4 * 256;
+  static_assert(2 * XB4 <= NS * STAGE4, "exchange buffers");
+  const int widx = (ng * 4 + mu) * 256 + l31 * 8;   // + ((2 g + half) ^ (unit & 7))
+  const int rng = t >> 8, run = (t >> 3) & 31, rcg = t & 7;   // reader: channel tile, unit, 4-channel group
+  const int ridx = rng * 1024 + run * 8 + (rcg ^ (run & 7));  // + mu * 256
+  const int nrd = n0 + rng * 32 + rcg * 4;
+  const float b0 = p.bias[nrd], b1 = p.bias[nrd + 1], b2 = p.bias[nrd + 2], b3 = p.bias[nrd + 3];
+  const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
+  float* const orow = p.out + (((size_t)img * p.H + oy) * p.W + ox) * p.ostride + nrd;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-      o[r] = j == 0 ? ((m0 + m1) + m2) + (m3 + m4) : j == 1 ? (m1 - m2) + 2.f * (m3 - m4) : j == 2 ? (m1 + m2) + 4.f * (m3 + m4)
-                                                                                          : (m1 - m2) + (8.f * (m3 - m4) + m5);
-    }
-    if (j) __syncthreads();            // the previous round has been consumed
-    if (mu == 1 || mu == 2) {
-      float* give = xbuf + ((ng * 2 + (mu - 1)) * 16) * 64 + lane;
+  for (int jx = 0; jx < 4; ++jx) {
+    bf4* const xw = xb + (jx & 1) * XB4;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) give[r * 64] = o[r];
+    for (int g = 0; g < 4; ++g) {
+      bf4 v;
+      v[0] = o[jx][4 * g]; v[1] = o[jx][4 * g + 1]; v[2] = o[jx][4 * g + 2]; v[3] = o[jx][4 * g + 3];
+      xw[widx + ((2 * g + half) ^ (l31 & 7))] = v;
     }
     __syncthreads();
-    if (mu == 0 || mu == 3) {
-      const float* t1 = xbuf + ((ng * 2 + 0) * 16) * 64 + lane;
-      const float* t2 = xbuf + ((ng * 2 + 1) * 16) * 64 + lane;
+    const bf4 m0 = xw[ridx], m1 = xw[ridx + 256], m2 = xw[ridx + 512], m3 = xw[ridx + 768];
+    bf4 r0, r1;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float m1 = t1[r * 64], m2 = t2[r * 64];
-        float v = mu == 0 ? (o[r] + m1) + m2 : (m1 - m2) - o[r];
-        const int unit = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int y = y0 + 2 * (unit / QW) + (mu == 3 ? 1 : 0);
-        const int x = x0 + 4 * (unit % QW) + j;
-        v += bv;
-        if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-        if (y < p.H && x < p.W) p.out[(((size_t)img * p.H + y) * p.W + x) * p.ostride + n] = v;
-      }
+    for (int c = 0; c < 4; ++c) {
+      const float bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
+      float v0 = ((m0[c] + m1[c]) + m2[c]) + bv, v1 = ((m1[c] - m2[c]) - m3[c]) + bv;
+      if (p.leaky) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
+      r0[c] = v0; r1[c] = v1;
+    }
+    if (ox + jx < p.W) {
+      float* const o0 = orow + (size_t)jx * p.ostride;
+      if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
+      if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * p.ostride) = r1;
+    }
+  }
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) {
+    const unsigned long long tm3 = __builtin_readcyclecounter();
+    if (t == 0) {
+      unsigned long long* o8 = reinterpret_cast<unsigned long long*>(p.part) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
+      o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3;
     }
   }
 }
 
-template <int TH, int BN, int FLAGS, int QW = 8>
+template <int BN, int FLAGS>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
-  constexpr int NWL = 4 * (BN / 32), NIL = ((TH + 2) * (4 * QW + 2) + 15) / 16;
-  constexpr size_t r_bytes = (FLAGS & W2D_F_RAW) ? 2 * (size_t)(((NIL + NWL - 1) / NWL) * NWL) * 1024 : 0;
-  constexpr size_t a_bytes = ((FLAGS & W2D_F_MIDBAR) ? 3 : 2) * (size_t)(TH + 2) * 6 * QW * 8 * sizeof(float) + r_bytes;
-  constexpr size_t x_bytes = (size_t)(BN / 32) * 2 * 16 * 64 * sizeof(float);
-  constexpr size_t lds = a_bytes > x_bytes ? a_bytes : x_bytes;
+  constexpr size_t lds = 3 * 24 * 1024;   // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside
   constexpr int NT = 4 * (BN / 32) * 64;
-  static_assert(lds <= (BN == 32 ? 80 : 160) * 1024, "LDS (two workgroups per CU with BN = 32)");
-  if constexpr ((FLAGS & W2D_F_RAW) != 0) {
-    if (p.Ctot % 16) return hipErrorInvalidValue;
-    for (int i = 0; i < p.nseg; ++i)
-      if (p.seg[i].C % 16 || p.seg[i].stride % 16 || p.seg[i].up) return hipErrorInvalidValue;
+  if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 16 || p.Cout % BN || p.pool_out || p.pw_out) return hipErrorInvalidValue;
+  if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
+  for (int i = 0; i < p.nseg; ++i)
+    if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
+  auto kern = conv_wino2d_kernel<BN, FLAGS>;
+  static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 8 || p.Cout % BN) return hipErrorInvalidValue;
-  auto kern = conv_wino2d_kernel<TH, BN, FLAGS, QW>;
-  if constexpr (lds > 64 * 1024) {
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
-  }
-  const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
+  const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, 1);
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();

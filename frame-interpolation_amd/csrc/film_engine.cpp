@@ -165,21 +165,9 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
   return out;
 }
 
-static bool wino2d_raw_ok(const OpDesc& op) {
-  for (int i = 0; i < op.nseg; ++i)
-    if (op.seg[i].v.C % 16 || op.seg[i].v.stride % 16 || op.seg[i].v.off % 4 || op.seg[i].up) return false;
-  return op.Ctot % 16 == 0;
-}
-
-std::vector<int> wino2d_candidates(int Cout, bool raw_ok) {
-  std::vector<int> shapes = Cout % 64 == 0 ? std::vector<int>{W2D_Q8_8x64, W2D_Q8_8x32, W2D_Q16_4x64, W2D_Q16_4x32} : std::vector<int>{W2D_Q8_8x32, W2D_Q16_4x32};
-  shapes.push_back(W2D_Q8_8x32_M);
-  if (raw_ok) {   // raw LDS staging (whole 64-B sectors): every segment a multiple of 16 channels at a 64-B pixel stride
-    shapes.push_back(W2D_Q8_8x32_R);
-    if (Cout % 64 == 0) { shapes.push_back(W2D_Q8_8x64_R); shapes.push_back(W2D_Q8_8x64_RM); }
-  }
+std::vector<int> wino2d_candidates(int Cout) {
   std::vector<int> out;
-  for (int sh : shapes) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
+  for (int sh : (Cout % 64 == 0 ? std::vector<int>{W2D_8x64, W2D_8x32} : std::vector<int>{W2D_8x32})) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
   return out;
 }
 
@@ -229,7 +217,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
-  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, wino2d_raw_ok(op)) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
   if (op.c3) {
     // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
     // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
@@ -558,7 +546,7 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "w2d_shape")) {
-    if (value < -1 || value > 15) return fail(h, FILM_ERR_INVALID, "w2d_shape: -1 (autotuned) or a Wino2dTile shape index");
+    if (value < -1 || value >= W2D_SHAPES) return fail(h, FILM_ERR_INVALID, "w2d_shape: -1 (autotuned) or a Wino2dTile shape index");
     if ((int)value != h->opt_w2d_shape) {  // plans carry the tile choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());

@@ -223,14 +223,9 @@ enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_
                   /* ids >= 16 carry CONV_TILE_EXT in the tile id (shape = (tile & 15) + 16).  The 32-channel Q8 tile WITH the
                      weight ring: 48 KB of LDS, 152 VGPRs -> three workgroups per CU (flow level 0 conv_0: -7 % against the BG tile) */
                   W43_Q8_8x32_T11_P2 = 16 };
-// conv_wino2d_kernel tiles (CONV_TILE_W2D): one 32-unit MFMA row tile (unit = 2 rows x 4 pixels) x output channels; Q8 = 8 rows x
-// 32 pixels, Q16 = 4 rows x 64 pixels; 64 channels = 8 waves (one workgroup per CU), 32 channels = 4 waves (two per CU).
-// _R: the halo patch is staged RAW in LDS first (W2D_F_RAW: buffer_load ... lds, whole 64-B sectors), the x transform reads it
-// from there - same arithmetic, same bits; needs every input segment's C and pixel stride % 16 == 0
-// _M / _RM: three activation stages, the chunk's barrier behind nu step 3 and the next chunk's first fragment read during step 5
-// (W2D_F_MIDBAR; with raw staging only as the 64-channel tile: 93 KB of LDS, one workgroup per CU)
-enum Wino2dTile { W2D_Q8_8x64 = 0, W2D_Q8_8x32 = 1, W2D_Q16_4x64 = 2, W2D_Q16_4x32 = 3, W2D_Q8_8x64_R = 4, W2D_Q8_8x32_R = 5,
-                  W2D_Q8_8x64_RM = 6, W2D_Q8_8x32_M = 7 };
+// conv_wino2d_kernel tiles (CONV_TILE_W2D): one 32-unit MFMA tile (unit = 2 rows x 4 pixels; 8 rows x 32 pixels) x output channels;
+// 64 channels = 8 waves (one workgroup per CU), 32 channels = 4 waves (two per CU).  Same sums: the autotuner picks freely.
+enum Wino2dTile { W2D_8x64 = 0, W2D_8x32 = 1, W2D_SHAPES = 2 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

@@ -162,12 +162,17 @@ struct Planner {
     // enough to fill the chip without split-K.  A family of its own (a function of the layer and the level size only).
     // (Round 3, second half: no longer tied to the 1-D kernel's own thresholds - a 64-channel layer needed 30 000 pixels for those,
     // which left K = 384 -> 64 of flow level 1 on the direct kernel for 448x256 and 256x256 frames.)
-    if (L.w2d_off >= 0 && w2d_ok && !any_up && h->opt_precision == 0 && op.split == 0 &&
+    // conv_wino2d_kernel moves the halo patch by DMA in 16-channel pieces and stores four channels per lane: every input segment
+    // a multiple of 16 channels at 16-byte aligned pixels, a 16-byte aligned output slice (true of every such layer of the
+    // published net; a property of the layer's buffers, so still a function of the layer only)
+    bool w2d_layout = ctot % 16 == 0 && out.off % 4 == 0 && out.stride % 4 == 0;
+    for (int i = 0; i < op.nseg; ++i) w2d_layout = w2d_layout && segs[i].v.C % 16 == 0 && segs[i].v.off % 4 == 0 && segs[i].v.stride % 4 == 0;
+    if (L.w2d_off >= 0 && w2d_ok && w2d_layout && !any_up && h->opt_precision == 0 && op.split == 0 &&
         (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= 8192)))
       op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
-    op.tile = op.wino == 4 ? ((L.cout % 64 == 0 ? W2D_Q8_8x64 : W2D_Q8_8x32) | CONV_TILE_W2D | CONV_TILE_XCD)
+    op.tile = op.wino == 4 ? ((L.cout % 64 == 0 ? W2D_8x64 : W2D_8x32) | CONV_TILE_W2D | CONV_TILE_XCD)
               : op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_BG) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)
               : op.wino == 2 ? ((L.cout % 128 == 0 ? WX3_4x128_T22 : L.cout % 64 == 0 ? WX3_4x64_T12 : WX3_4x32_T11) | CONV_TILE_WINO | CONV_TILE_X3 | CONV_TILE_XCD)
               : op.wino ? ((L.cout % 64 == 0 ? WINO_4x64_W8 : WINO_4x32) | CONV_TILE_WINO | CONV_TILE_XCD)

@@ -1,0 +1,244 @@
+// w2d_bench.hip -- micro-benchmark + bit-identity check of the nested-Winograd kernels (round 3's conv_wino2d_r3_kernel tiles against
+// conv_wino2d_kernel) on the layer shapes they run in a 1080p 2x2-tiled forward, plus a two-segment input with a batch remap
+// and a ragged level.  Development tool (lean sibling of conv_bench.hip: compiles in a minute), not part of the product library.
+//
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/w2d_bench.hip -o tools/bin/w2d_bench
+//   tools/bin/w2d_bench [reps] [shape index | -1] [variant substring[,substring...]]
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "retired/conv_wino2d_r3_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_wino2d_impl.h"
+
+#define CK(x)                                                                              \
+  do {                                                                                     \
+    hipError_t e_ = (x);                                                                   \
+    if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } \
+  } while (0)
+
+__global__ void fill_kernel(float* dst, size_t n, unsigned seed, float scale) {
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (; i < n; i += stride) {
+    unsigned x = (unsigned)i * 2654435761u ^ seed ^ (unsigned)(i >> 32) * 40503u;
+    x ^= x >> 15; x *= 2246822519u; x ^= x >> 13; x *= 3266489917u; x ^= x >> 16;
+    dst[i] = (float)(int)x * (1.0f / 2147483648.0f) * scale;
+  }
+}
+
+__global__ void checksum_kernel(const float* a, size_t n, double* out) {
+  __shared__ double sh[256];
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) s += fabs((double)a[i]);
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) sh[threadIdx.x] += sh[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(out, sh[0]);
+}
+
+// [tap*C + c][N] -> [N/32][chunk8][mu 4][nu 6][K half][32][4]: F(4,3) along x, then F(2,3) along y (conv_wino2d_impl.h)
+__global__ void pack_wino2d_kernel(const float* src, float* dst, int C, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)C * N) return;
+  const int n = (int)(i % N), c = (int)(i / N);
+  float u[3][6];
+  for (int dy = 0; dy < 3; ++dy) {
+    const float g0 = src[((size_t)(dy * 3 + 0) * C + c) * N + n], g1 = src[((size_t)(dy * 3 + 1) * C + c) * N + n],
+                g2 = src[((size_t)(dy * 3 + 2) * C + c) * N + n];
+    u[dy][0] = g0 * 0.25f;
+    u[dy][1] = -((g0 + g2) + g1) * (1.f / 6.f);
+    u[dy][2] = -((g0 + g2) - g1) * (1.f / 6.f);
+    u[dy][3] = (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) + g1 * (1.f / 12.f);
+    u[dy][4] = (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) - g1 * (1.f / 12.f);
+    u[dy][5] = g2;
+  }
+  for (int nu = 0; nu < 6; ++nu) {
+    const float U[4] = {u[0][nu], ((u[0][nu] + u[2][nu]) + u[1][nu]) * 0.5f, ((u[0][nu] + u[2][nu]) - u[1][nu]) * 0.5f, u[2][nu]};
+    for (int mu = 0; mu < 4; ++mu)
+      dst[(((((size_t)(n / 32) * (C / 8) + c / 8) * 4 + mu) * 6 + nu) * 2 + (c % 8) / 4) * 128 + (n % 32) * 4 + c % 4] = U[mu];
+  }
+}
+
+__global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
+  float m = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const float d = fabsf(a[i] - b[i]);
+    m = fmaxf(m, d == d ? d : 1e30f);   // NaN counts as a difference
+  }
+  atomicMax(reinterpret_cast<unsigned*>(out), __float_as_uint(m));  // non-negative floats order like unsigned ints
+}
+
+typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
+// fam 0: the bits of round 3's conv_wino2d_r3_kernel (reference = the first variant run); fam 1: conv_wino2d_kernel's own family (reference = the
+// first fam-1 variant run; its distance from family 0 is printed); fam -1: timing ablation (wrong on purpose)
+struct Variant { const char* name; int bn; int fam; LaunchFn fn; };
+constexpr int SCHED = W2R_F_ILV | W2R_F_LATE | W2R_F_B2;
+constexpr int MIDF = W2R_F_ILV | W2R_F_B2 | W2R_F_MIDBAR;
+#define W2D(NAME, BN, FL) {"r3  " NAME, BN, 0, conv_wino2d_r3_launch<8, BN, FL, 8>}
+#define W2N(NAME, BN, FL) {"w2d " NAME, BN, ((FL) & 0x3F00) ? -1 : ((FL) & W2D_F_XFIRST) ? 0 : 1, conv_wino2d_launch<BN, FL>}
+static Variant variants[] = {
+    W2D("8x64_RM", 64, 4 | MIDF | W2R_F_RAW), W2D("8x32_R", 32, 4 | SCHED | W2R_F_RAW), W2D("8x32_M", 32, 4 | MIDF), W2D("8x64_R", 64, 4 | SCHED | W2R_F_RAW),
+    W2D("8x64_RM plain", 64, MIDF | W2R_F_RAW), W2D("8x32_R plain", 32, SCHED | W2R_F_RAW),
+    W2N("64 xf", 64, 4 | W2D_F_XFIRST), W2N("32 xf", 32, 4 | W2D_F_XFIRST),
+    W2N("64", 64, 4), W2N("32", 32, 4), W2N("64 plain", 64, 0), W2N("32 plain", 32, 0),
+    W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
+    W2N("64 abl-noxf", 64, 4 | W2D_DBG_NOXF), W2N("32 abl-noxf", 32, 4 | W2D_DBG_NOXF),
+    W2N("64 abl-nodma", 64, 4 | W2D_DBG_NODMA), W2N("32 abl-nodma", 32, 4 | W2D_DBG_NODMA),
+    W2N("64 abl-nob", 64, 4 | W2D_DBG_NOB), W2N("32 abl-nob", 32, 4 | W2D_DBG_NOB),
+    W2N("64 abl-nobar", 64, 4 | W2D_DBG_NOBAR), W2N("32 abl-nobar", 32, 4 | W2D_DBG_NOBAR),
+    W2N("64 abl-nord", 64, 4 | W2D_DBG_NORD | W2D_DBG_NOXF), W2N("32 abl-nord", 32, 4 | W2D_DBG_NORD | W2D_DBG_NOXF),
+    W2N("64 abl-mfma", 64, 4 | W2D_DBG_NORD | W2D_DBG_NOXF | W2D_DBG_NODMA | W2D_DBG_NOB | W2D_DBG_NOBAR),
+    W2N("32 abl-mfma", 32, 4 | W2D_DBG_NORD | W2D_DBG_NOXF | W2D_DBG_NODMA | W2D_DBG_NOB | W2D_DBG_NOBAR),
+};
+
+// C2 > 0: the input is two segments, [C - C2 channels of buffer A | C2 channels of buffer B read with the batch halves swapped]
+struct Shape { const char* name; int NB, H, W, C, Cout, C2; };
+static Shape shapes[] = {
+    {"fusion_1_1  4x288x480  528->128", 4, 288, 480, 528, 128, 0},
+    {"fusion_3_1  4x72x120  2448->512", 4, 72, 120, 2448, 512, 0},
+    {"flow_l3_c0  8x72x120  1920->256", 8, 72, 120, 1920, 256, 0},
+    {"fusion_2_1  4x144x240 1168->256", 4, 144, 240, 1168, 256, 0},
+    {"flow_l2_c0  8x144x240  896->128", 8, 144, 240, 896, 128, 0},
+    {"flow_l1_c0  8x288x480  384->64", 8, 288, 480, 384, 64, 0},
+    {"fusion_0_1  4x576x960  208->64", 4, 576, 960, 208, 64, 0},
+    {"flow_l0_c0  8x576x960  128->32", 8, 576, 960, 128, 32, 0},
+    {"fusion_2_2  4x144x240  256->256", 4, 144, 240, 256, 256, 0},
+    {"feat_conv7  8x72x120   512->512", 8, 72, 120, 512, 512, 0},
+    {"two-seg     4x144x240  (96|48)->64, batch halves swapped in seg 1", 4, 144, 240, 144, 64, 48},
+    {"ragged      3x36x60    64->64", 3, 36, 60, 64, 64, 0},
+    {"ragged2     2x50x70    (32|16)->32", 2, 50, 70, 48, 32, 16},
+};
+
+int main(int argc, char** argv) {
+  const int reps = argc > 1 ? atoi(argv[1]) : 3;
+  const int only_shape = argc > 2 ? atoi(argv[2]) : -1;      // -1: all shapes
+  const char* only_variant = argc > 3 ? argv[3] : nullptr;   // substring filter on the variant name
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  double* d_sum;
+  CK(hipMalloc(&d_sum, sizeof(double)));
+  int shape_idx = -1, bad = 0;
+  for (const Shape& sh : shapes) {
+    if (++shape_idx != only_shape && only_shape >= 0) continue;
+    const size_t M = (size_t)sh.NB * sh.H * sh.W;
+    const int C1 = sh.C - sh.C2;
+    const int strideA = C1 + 16, strideB = sh.C2 ? sh.C2 + 32 : 0;   // the segments are channel slices of wider buffers
+    const size_t n_a = M * strideA, n_b = M * strideB, n_w = (size_t)9 * sh.C * sh.Cout, n_out = M * sh.Cout;
+    float *d_a, *d_bb = nullptr, *d_w, *d_w2d, *d_b, *d_out, *d_ref, *d_ref1, *d_md;
+    CK(hipMalloc(&d_a, n_a * 4));
+    if (n_b) CK(hipMalloc(&d_bb, n_b * 4));
+    CK(hipMalloc(&d_w, n_w * 4));
+    CK(hipMalloc(&d_w2d, n_w * 4 * 24 / 9 + 64));
+    CK(hipMalloc(&d_ref, n_out * 4));
+    CK(hipMalloc(&d_ref1, n_out * 4));
+    CK(hipMalloc(&d_md, 4));
+    CK(hipMalloc(&d_b, sh.Cout * 4));
+    CK(hipMalloc(&d_out, n_out * 4));
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_a, n_a, 1u, 1.0f);
+    if (n_b) hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_bb, n_b, 7u, 1.0f);
+    hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_w, n_w, 2u, 0.05f);
+    hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, st, d_b, (size_t)sh.Cout, 3u, 0.1f);
+    hipLaunchKernelGGL(pack_wino2d_kernel, dim3((unsigned)((n_w / 9 + 255) / 256)), dim3(256), 0, st, d_w, d_w2d, sh.C, sh.Cout);
+    CK(hipStreamSynchronize(st));
+    unsigned long long* d_tm;
+    const size_t n_tm = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / 32) * 8;
+    CK(hipMalloc(&d_tm, n_tm * 8));
+    ConvParams p{};
+    p.part = reinterpret_cast<float*>(d_tm);
+    p.nseg = sh.C2 ? 2 : 1;
+    p.seg[0].ptr = d_a + 16; p.seg[0].stride = strideA; p.seg[0].C = C1;
+    if (sh.C2) { p.seg[1].ptr = d_bb + 16; p.seg[1].stride = strideB; p.seg[1].C = sh.C2; p.seg[1].boff = sh.NB / 2; p.seg[1].bmod = sh.NB; }
+    p.ksize = 3; p.w = d_w2d; p.bias = d_b; p.out = d_out; p.ostride = sh.Cout;
+    p.NB = sh.NB; p.H = sh.H; p.W = sh.W; p.Cout = sh.Cout; p.Ctot = sh.C; p.leaky = 1; p.M = (int)M;
+    const double flops = 2.0 * M * sh.Cout * 9 * sh.C;
+    printf("== %d %s  (%.1f GFLOP direct)\n", shape_idx, sh.name, flops * 1e-9);
+    bool have_ref[2] = {false, false};
+    for (const Variant& v : variants) {
+      if (sh.Cout % v.bn) continue;
+      if (only_variant) {   // comma-separated substrings: any match
+        bool hit = false;
+        std::string flt(only_variant);
+        for (size_t b = 0; b <= flt.size();) {
+          const size_t e = flt.find(',', b) == std::string::npos ? flt.size() : flt.find(',', b);
+          if (e > b && strstr(v.name, flt.substr(b, e - b).c_str())) hit = true;
+          b = e + 1;
+        }
+        if (!hit) continue;
+      }
+      CK(hipMemsetAsync(d_out, 0xFF, n_out * 4, st));   // NaN: an unwritten output shows
+      hipError_t le = v.fn(p, st);
+      if (le != hipSuccess) { printf("   %-24s  refused (%s)\n", v.name, hipGetErrorString(le)); (void)hipGetLastError(); continue; }
+      CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
+      hipLaunchKernelGGL(checksum_kernel, dim3(1024), dim3(256), 0, st, d_out, n_out, d_sum);
+      double sum = 0;
+      CK(hipMemcpyAsync(&sum, d_sum, sizeof(double), hipMemcpyDeviceToHost, st));
+      CK(hipStreamSynchronize(st));
+      if (sum != sum) { printf("   %-24s  NaN in the output (unwritten element?)\n", v.name); ++bad; }
+      float maxdiff = 0.f, fam_dist = -1.f;
+      auto diff_to = [&](const float* ref) {
+        float md = 0.f;
+        CK(hipMemsetAsync(d_md, 0, 4, st));
+        hipLaunchKernelGGL(maxdiff_kernel, dim3(1024), dim3(256), 0, st, d_out, ref, n_out, d_md);
+        CK(hipMemcpyAsync(&md, d_md, 4, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        return md;
+      };
+      const int fam = v.fam < 0 ? 1 : v.fam;   // (ablations are variants of the y-first loop)
+      float* const refs[2] = {d_ref, d_ref1};
+      if (v.fam >= 0 && !have_ref[fam]) {
+        have_ref[fam] = true;
+        CK(hipMemcpyAsync(refs[fam], d_out, n_out * 4, hipMemcpyDeviceToDevice, st));
+        CK(hipStreamSynchronize(st));
+        if (fam == 1 && have_ref[0]) fam_dist = diff_to(d_ref);
+      } else if (have_ref[fam]) maxdiff = diff_to(refs[fam]);
+      float best = 1e30f, tot = 0;
+      for (int r = 0; r < reps; ++r) {
+        CK(hipEventRecord(e0, st));
+        CK(v.fn(p, st));
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        best = fminf(best, ms); tot += ms;
+      }
+      if (strstr(v.name, "time")) {   // per-workgroup phase times (shader clock ticks = 100 MHz s_memtime? printed raw) and the per-CU timeline
+        const size_t nwg = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / v.bn);
+        std::vector<unsigned long long> tm(nwg * 8);
+        CK(hipMemcpy(tm.data(), d_tm, nwg * 64, hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi = 0;
+        unsigned long long tmin = ~0ull, tmax = 0;
+        for (size_t i = 0; i < nwg; ++i) {
+          pro += (double)(tm[i * 8 + 1] - tm[i * 8]); loop += (double)(tm[i * 8 + 2] - tm[i * 8 + 1]); epi += (double)(tm[i * 8 + 3] - tm[i * 8 + 2]);
+          if (tm[i * 8] < tmin) tmin = tm[i * 8];
+          if (tm[i * 8 + 3] > tmax) tmax = tm[i * 8 + 3];
+        }
+        printf("   [time] %zu workgroups: prologue %.0f  K loop %.0f  epilogue %.0f ticks (averages); kernel span %llu ticks; ids of wg 0: hw_id %llx xcc %llx\n", nwg,
+               pro / nwg, loop / nwg, epi / nwg, tmax - tmin, tm[4], tm[5]);
+        // busy share of one CU slot: follow the workgroups that ran on the CU of workgroup 0 (same hw_id CU/SE bits and XCC)
+      }
+      const bool abl = v.fam < 0;
+      if (!abl && maxdiff != 0.f) ++bad;
+      printf("   %-24s  min %8.3f ms  avg %8.3f ms  %7.1f TF/s direct-eq  %s max|d| %.2e", v.name, best, tot / reps, flops / best * 1e-9,
+             abl ? "(ablation)" : maxdiff == 0.f ? (fam ? "bit-identical (family 1)" : "bit-identical (family 0)") : "MISMATCH", maxdiff);
+      if (fam_dist >= 0.f) printf("   [family 1 vs family 0: max|d| %.2e, checksum %.6e]", fam_dist, sum);
+      printf("\n");
+      fflush(stdout);
+    }
+    CK(hipFree(d_tm));
+    CK(hipFree(d_a)); if (d_bb) CK(hipFree(d_bb)); CK(hipFree(d_w)); CK(hipFree(d_w2d)); CK(hipFree(d_ref)); CK(hipFree(d_ref1)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
+  }
+  printf("mismatches: %d\n", bad);
+  return bad ? 1 : 0;
+}
