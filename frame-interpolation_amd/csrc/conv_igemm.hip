@@ -183,9 +183,9 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 
 static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = (tile & (CONV_TILE_XCD - 1)) + (((tile & CONV_TILE_EXT) && (tile & CONV_TILE_F43)) ? 16 : 0);
-  if ((p.pool_out != nullptr || p.pw_out != nullptr) && ((tile & CONV_TILE_W2D) || !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3)))) return hipErrorInvalidValue;
+  if ((p.pool_out != nullptr || p.pw_out != nullptr) && !(tile & CONV_TILE_W2D) && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
   if (tile & CONV_TILE_W2D) {
-    if (p.ksize != 3 || p.pool_out != nullptr || p.pw_out != nullptr) return hipErrorInvalidValue;
+    if (p.ksize != 3) return hipErrorInvalidValue;   // (fused pool / 1x1: checked by the launcher)
     return (tile & CONV_TILE_XCD) ? launch_wino2d<CONV_B_XCD_M>(p, shape, s) : launch_wino2d<0>(p, shape, s);
   }
   if (tile & CONV_TILE_FOLDX3) {

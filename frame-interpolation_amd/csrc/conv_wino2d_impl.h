@@ -392,6 +392,13 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const float b0 = p.bias[nrd], b1 = p.bias[nrd + 1], b2 = p.bias[nrd + 2], b3 = p.bias[nrd + 3];
   const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
   float* const orow = p.out + (((size_t)img * p.H + oy) * p.W + ox) * p.ostride + nrd;
+  // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
+  // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
+  // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][65] behind the exchange
+  // buffers instead of to `out`; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
+  float* const pool_base = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.pool_ostride + nrd : nullptr;
+  float* const pwt = smem + 2 * XB4 * 4;
+  bf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int jx = 0; jx < 4; ++jx) {
     bf4* const xw = xb + (jx & 1) * XB4;
@@ -411,10 +418,47 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       if (p.leaky) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
       r0[c] = v0; r1[c] = v1;
     }
-    if (ox + jx < p.W) {
-      float* const o0 = orow + (size_t)jx * p.ostride;
-      if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
-      if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * p.ostride) = r1;
+    if (p.pw_out == nullptr) {
+      if (ox + jx < p.W) {
+        float* const o0 = orow + (size_t)jx * p.ostride;
+        if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
+        if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * p.ostride) = r1;
+      }
+      if (pool_base != nullptr) {
+        if (jx & 1) {
+          bf4 pv;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) pv[c] = (((k0[c] + r0[c]) + k1[c]) + r1[c]) * 0.25f;
+          if (oy < p.H && ox + jx < p.W) *reinterpret_cast<bf4*>(pool_base + (size_t)(jx >> 1) * p.pool_ostride) = pv;
+        } else {
+          k0 = r0; k1 = r1;
+        }
+      }
+    } else {
+      float* const tr = pwt + ((2 * (run >> 3)) * PXW + 4 * (run & 7) + jx) * 65 + rng * 32 + rcg * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { tr[c] = r0[c]; tr[PXW * 65 + c] = r1[c]; }
+    }
+  }
+  if (p.pw_out != nullptr) {
+    __syncthreads();
+    if (t < TH * PXW) {
+      const int y = y0 + t / PXW, x = x0 + (t % PXW);
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* row = pwt + t * 65;
+#pragma unroll 8
+      for (int c = 0; c < 64; ++c) {
+        const float v = row[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < p.pw_cout) a[j] = __builtin_fmaf(v, p.pw_w[c * p.pw_cout + j], a[j]);
+      }
+      if (y < p.H && x < p.W) {
+        float* dd = p.pw_out + (((size_t)img * p.H + y) * p.W + x) * p.pw_ostride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (j < p.pw_cout) dd[j] = a[j] + p.pw_bias[j];
+      }
     }
   }
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) {
@@ -428,10 +472,14 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 
 template <int BN, int FLAGS>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
-  constexpr size_t lds = 3 * 24 * 1024;   // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside
+  // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside; the fused 1x1 adds its [256][65] tile behind them
+  const size_t lds = p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 65 * 4 : (size_t)3 * 24 * 1024;
   constexpr int NT = 4 * (BN / 32) * 64;
-  if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 16 || p.Cout % BN || p.pool_out || p.pw_out) return hipErrorInvalidValue;
-  if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
+  if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 16 || p.Cout % BN) return hipErrorInvalidValue;
+  if (p.pw_out) {   // a workgroup must hold every channel of its pixels
+    if (BN != 64 || p.Cout != 64 || p.pool_out || p.pw_cout < 1 || p.pw_cout > 4) return hipErrorInvalidValue;
+  } else if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
+  if (p.pool_out && ((p.H | p.W) & 1 || p.pool_ostride % 4 || (reinterpret_cast<uintptr_t>(p.pool_out) & 15))) return hipErrorInvalidValue;
   for (int i = 0; i < p.nseg; ++i)
     if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
   auto kern = conv_wino2d_kernel<BN, FLAGS>;
@@ -439,7 +487,7 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }

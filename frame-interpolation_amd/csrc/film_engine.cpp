@@ -165,9 +165,9 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
   return out;
 }
 
-std::vector<int> wino2d_candidates(int Cout) {
+std::vector<int> wino2d_candidates(int Cout, bool pw = false) {
   std::vector<int> out;
-  for (int sh : (Cout % 64 == 0 ? std::vector<int>{W2D_8x64, W2D_8x32} : std::vector<int>{W2D_8x32})) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
+  for (int sh : (pw ? std::vector<int>{W2D_8x64} /* the fused 1x1 needs every channel of a pixel in one workgroup */ : Cout % 64 == 0 ? std::vector<int>{W2D_8x64, W2D_8x32} : std::vector<int>{W2D_8x32})) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
   return out;
 }
 
@@ -217,7 +217,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
-  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, op.pw_out.buf >= 0) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
   if (op.c3) {
     // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
     // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists

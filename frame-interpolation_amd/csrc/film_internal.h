@@ -113,7 +113,7 @@ struct LayerPack {
   int64_t wfx_off = -1;      // 2x2 layers after an upsample: the phase-summed weights as bf16 hi / mid for conv_foldx3_kernel,
                              //     [Cout][ctot/16][9 (tap, phase) steps][plane][16] bf16
   int64_t w43_off = -1;      // ... the F(4,3)-along-x transformed copy for conv_wino43_kernel, [Cout][ctot/8][3 dy][6 nu][8]
-  int64_t w2d_off = -1;      // deep-K layers (has_w2d): the nested F(4,3)x x F(2,3)y copy for conv_wino2d_kernel,
+  int64_t w2d_off = -1;      // has_w2d layers: the nested F(4,3)x x F(2,3)y copy for conv_wino2d_kernel,
                              //     [Cout/32][ctot/8][mu 4][nu 6][K half][32][4] (24 values per (ci, co): 2.67x the kernel)
   int64_t wx_off = -1;       // ... and the transformed copy split into bf16 hi / mid for conv_winox3_kernel,
                              //     [Cout][ctot/16][dy][j][h][plane][16] bf16 (nu = 2h + j)
@@ -121,10 +121,10 @@ struct LayerPack {
                              //     (offset in floats; 1.5 floats per weight)
   bool has_halo() const { return kmajor() && kh == 3 && kw == 3; }
   bool has_fold() const { return kmajor() && kh == 2 && kw == 2; }
-  // conv_wino2d_kernel against the best 1-D F(4,3) tile of the same run (tools/conv_bench.hip, profiles/r03_conv_bench_w2d.log):
-  // 1.12-1.24x at K = 384 ... 2448, 1.06x at 256 -> 256, 1.02x at 208 -> 64, 1.17x at 128 -> 32 (where the 1-D kernel's
-  // 32-channel tile is weak), 0.97x at 128 -> 128, 0.85x at K = 64 (its activation staging per MFMA is 1.5x the 1-D kernel's)
-  bool has_w2d() const { return has_halo() && (ctot() >= 208 || (ctot() >= 128 && cout == 32)); }
+  // conv_wino2d_kernel against the best 1-D F(4,3) tile of the same run (tools/w2d_bench.hip, profiles/r04_w2d_vs_w43.log): 16-30 %
+  // faster on EVERY 3x3 layer of the 1080p plan, K = 32 ... 2448 (round 3's kernel lost below K = 208: its four-round epilogue of dword
+  // stores cost 26 000 cycles per workgroup) - every 3x3 layer whose channels come in sixteens and thirty-twos carries the copy
+  bool has_w2d() const { return has_halo() && ctot() % 16 == 0 && cout % 32 == 0; }
   int ctot() const { return (int)perm.size(); }
   int64_t packed_rows() const { return c3 ? 48 : (int64_t)kh * kw * ctot(); }
 };

@@ -25,7 +25,6 @@ struct Planner {
 
   bool bad = false;
   std::string bad_msg;
-  bool w2d_ok = true;   // cleared by the caller for a layer whose epilogue fusion (average pool) only conv_wino43_kernel has
 
   int add_buffer(const std::string& name, int N, int H, int W, int C) {
     Buffer b{name, cursor, N, H, W, C, (int64_t)N * H * W * C};
@@ -167,7 +166,7 @@ struct Planner {
     // published net; a property of the layer's buffers, so still a function of the layer only)
     bool w2d_layout = ctot % 16 == 0 && out.off % 4 == 0 && out.stride % 4 == 0;
     for (int i = 0; i < op.nseg; ++i) w2d_layout = w2d_layout && segs[i].v.C % 16 == 0 && segs[i].v.off % 4 == 0 && segs[i].v.stride % 4 == 0;
-    if (L.w2d_off >= 0 && w2d_ok && w2d_layout && !any_up && h->opt_precision == 0 && op.split == 0 &&
+    if (L.w2d_off >= 0 && w2d_layout && !any_up && h->opt_precision == 0 && op.split == 0 &&
         (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= 8192)))
       op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
@@ -333,13 +332,11 @@ struct Planner {
         }
         SegDesc s1; s1.v = tmp;
         View dst = view(feat[lv], 0, slot_offset(c, j), k);
-        w2d_ok = !(j < n - 1 && (h->opt_fuse & 8));   // a pooled stage keeps the kernel that fuses the pool into its epilogue
         conv(tg, w1, {s1}, dst, N2, HL(lv), WL(lv), true);
-        w2d_ok = true;
         if (j < n - 1) {
           OpDesc& cv = P->ops.back();
-          if ((h->opt_fuse & 8) && cv.kind == OP_CONV && cv.wino == 3 && cv.ksplit <= 1 && !(HL(lv) & 1) && !(WL(lv) & 1)) {
-            // AveragePooling2D in the epilogue of the F(4,3) kernel (its 64-pixel tiles hold both rows of a 2x2 block)
+          if ((h->opt_fuse & 8) && cv.kind == OP_CONV && (cv.wino == 3 || cv.wino == 4) && cv.ksplit <= 1 && !(HL(lv) & 1) && !(WL(lv) & 1)) {
+            // AveragePooling2D in the epilogue of the Winograd kernels (a lane / thread holds both rows of a 2x2 block)
             cv.tag += "+pool";
             cv.out2 = scratch(fx_p, k);
           } else
@@ -519,16 +516,16 @@ struct Planner {
     }
     {
       // RGB head (fusion.py:138-140): a 1x1 convolution of the last decoder layer.  Fused (option fuse bit 16) into that
-      // layer's epilogue when it runs on conv_wino43_kernel with 64 output channels and no split: the 64-channel
+      // layer's epilogue when it runs on a Winograd kernel with 64 output channels and no split: the 64-channel
       // activation (566 MB per 1080p step) is then neither written nor read back.
       OpDesc& last = P->ops.back();
       const LayerPack& LO = h->layers[h->layer_idx.at("fusion/output_conv")];
-      if ((h->opt_fuse & 16) && last.kind == OP_CONV && last.wino == 3 && last.Cout == 64 && last.ksplit <= 1 && last.out2.buf < 0 &&
+      if ((h->opt_fuse & 16) && last.kind == OP_CONV && (last.wino == 3 || last.wino == 4) && last.Cout == 64 && last.ksplit <= 1 && last.out2.buf < 0 &&
           LO.cout <= 4 && LO.cin == 64) {
         last.tag += "+output_conv";
         last.pw_out = view(out, 0, 0, 3); last.pw_cout = LO.cout;
         last.w2_off = LO.w_off; last.b2_off = LO.b_off;
-        last.tile = W43_Q16_4x64_N1_P2 | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD;
+        last.tile = last.wino == 4 ? (W2D_8x64 | CONV_TILE_W2D | CONV_TILE_XCD) : (W43_Q16_4x64_N1_P2 | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD);
         last.flops += 2.0 * (double)B * H * W * LO.cout * LO.cin;
         last.bytes = 4.0 * (double)B * H * W * (64 + LO.cout);
       } else {

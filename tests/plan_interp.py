@@ -156,7 +156,7 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             bias = packed[op['b_off']:op['b_off'] + co]
             y = fo.conv2d_same(x, wt, bias, 'leaky' if op['leaky'] else None)
             if op.get('pw_out', {}).get('buf'):     # fused 1x1 convolution (the RGB head): `out` is NOT written
-                assert op.get('wino') == 3 and co == 64 and op.get('ksplit', 1) <= 1 and not op.get('out2', {}).get('buf')
+                assert op.get('wino') in (3, 4) and co == 64 and op.get('ksplit', 1) <= 1 and not op.get('out2', {}).get('buf')
                 c2 = op['pw_cout']
                 w2 = packed[op['w2_off']:op['w2_off'] + co * c2].reshape(1, 1, co, c2)
                 b2 = packed[op['b2_off']:op['b2_off'] + c2]
@@ -164,7 +164,7 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
                 continue
             _view(arena, op['out'], nb, h, w)[...] = y
             if op.get('out2', {}).get('buf'):       # fused AveragePooling2D(2, 2) of the output
-                assert op.get('wino') == 3 and h % 2 == 0 and w % 2 == 0
+                assert op.get('wino') in (3, 4) and h % 2 == 0 and w % 2 == 0
                 _view(arena, op['out2'], nb, h // 2, w // 2)[...] = fo.avg_pool2x2(y)
         elif k == 'flow_head':
             m = op['n']

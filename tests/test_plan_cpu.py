@@ -88,7 +88,7 @@ def test_set_weight_validation(tiny_weights):
     n1 = eng.export_layouts().size
     for e in (eng, eng2):
         e.set_option('pack_groups', 4)
-    assert eng.export_layouts().size > 2 * n1 and np.array_equal(eng2.export_layouts(), eng.export_layouts())
+    assert eng.export_layouts().size > 1.5 * n1 and np.array_equal(eng2.export_layouts(), eng.export_layouts())
     assert np.array_equal(eng.export_layouts()[:n1], eng2.export_layouts()[:n1])
 
 
@@ -194,7 +194,10 @@ def test_plan_interpreter_matches_oracle_published_64(published_packed):
     w2d_ops = [o for o in plan3['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4]
     assert len(w2d_ops) >= 8 and all(o['w2d_off'] >= 0 and (o['tile'] & 8192) for o in w2d_ops)
     tags, tags3 = [o['tag'] for o in plan['ops']], [o['tag'] for o in plan3['ops']]
-    assert sorted(tags) == sorted(tags3) and tags != tags3
+    # (the nested kernel also fuses the average pool behind a sub-extractor stage, which the direct kernel of a small level leaves to
+    # a pool launch: compare the plans without those)
+    strip = lambda ops: sorted(o['tag'].replace('+pool', '').replace('+output_conv', '') for o in ops if not (o['kind'] == 'pool' and o['tag'].startswith('feat_')) and o['tag'] != 'fusion_out:fusion/output_conv')
+    assert strip(plan['ops']) == strip(plan3['ops']) and tags != tags3
     assert {o['lane'] for o in plan3['ops'] if o['tag'].startswith(('fusion_l3', 'fusion_l2'))} == {1}
     assert {o['lane'] for o in plan3['ops'] if o['tag'].startswith(('fusion_l1', 'fusion_l0'))} == {0}
     arena3 = pi.run_plan(plan3, layouts, x0, x1)
@@ -221,7 +224,7 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
                 t = op['tile']
                 assert bool(t & FOLDX3) == (op['fold'] == 2 and op['split'] == 2)
                 assert bool(t & WINO) == (op['wino'] in (1, 2, 3)) and bool(t & SPLIT) == (op['split'] != 0 and not op['fold'])
-                assert bool(t & W2D) == (op['wino'] == 4) and (op['wino'] != 4 or (op['Ctot'] >= 128 and op['H'] * op['W'] >= 8192))
+                assert bool(t & W2D) == (op['wino'] == 4) and (op['wino'] != 4 or (op['Ctot'] % 16 == 0 and op['H'] * op['W'] >= 8192))
                 assert bool(t & X3) == (op['wino'] == 2 or (op['split'] == 2 and not op['fold']))
                 assert bool(t & F43) == (op['wino'] == 3)
         assert per_batch[0] == per_batch[1]
@@ -429,6 +432,7 @@ def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_w
     w2 = W.make_synthetic_weights(TINY, seed=11)
     eng = FilmEngine(TINY, device=-1)
     eng.set_weights(tiny_weights)
+    eng.set_option('wino2d', 0)                         # (the nested kernel reads group 0: without it the levels of this frame need F(2,3) / halo copies)
     base = eng.export_layouts().size
     kinds = {(op['halo'], op['wino']) for op in eng.plan(1, 128, 96)['ops'] if op['kind'] == 'conv_mfma'}
     grown = eng.export_layouts().size
@@ -441,15 +445,16 @@ def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_w
     assert after.size == grown and not np.array_equal(after, before)
     fresh = FilmEngine(TINY, device=-1)
     fresh.set_weights(w2)
+    fresh.set_option('wino2d', 0)
     fresh.plan(1, 128, 96)
     assert np.array_equal(after, fresh.export_layouts())
 
 
 def test_nested_winograd_rule_is_a_function_of_layer_and_level_size():
-    """conv_wino2d_kernel runs the layers that have the nested copy (K >= 208, or 128 -> 32) on levels with >= 8192 pixels - whatever
-    the batch size, and (round 3) also on small frames, where the 1-D kernel's own thresholds used to keep the 64-channel layers
-    on the direct kernel.  Pooled sub-extractor stages and levels below 8192 pixels never get it; "w2d_shape" forces one tile shape
-    where it fits and is validated."""
+    """conv_wino2d_kernel runs every 3x3 layer whose channels come in sixteens / thirty-twos (round 4: K = 32 ... 2448, pooled stages
+    and the RGB-head layer included - its epilogue fuses both) on levels with >= 8192 pixels - whatever the batch size, small frames
+    too.  Levels below 8192 pixels and the 3-channel first layers never get it; "w2d_shape" forces one tile shape where it fits and
+    is validated."""
     from film_hip.engine import FilmEngine, FilmError
     from film_hip.options import PUBLISHED
     eng = FilmEngine(PUBLISHED, device=-1)
@@ -461,18 +466,23 @@ def test_nested_winograd_rule_is_a_function_of_layer_and_level_size():
         one = nested(1, h, w)
         assert one == nested(3, h, w)                                  # never a function of the batch
         for tag, hh, ww in one:
-            assert hh * ww >= 8192 and '+pool' not in tag, (tag, hh, ww)
+            assert hh * ww >= 8192, (tag, hh, ww)
+        # ... and the other way round: every 3x3 layer of such a level that is not a first layer runs it
+        for o in eng.plan(1, h, w)['ops']:
+            if o['kind'] == 'conv_mfma' and o['ksize'] == 3 and not o.get('c3') and o['H'] * o['W'] >= 8192:
+                assert o['wino'] == 4, o['tag']
     small = [t for t, _, _ in nested(1, 256, 256)]
     assert any('flow_predictor_1/conv_0' in t for t in small) and any('flow_predictor_0/conv_0' in t for t in small), small
-    assert len(nested(4, 576, 960)) == 14
-    # every nested op of a plan also satisfies the rule the other way round: deep K or the 128 -> 32 layer
+    big = [t for t, _, _ in nested(4, 576, 960)]
+    assert len(big) == 36 and sum('+pool' in t for t in big) == 9 and any(t.endswith('convs_0_2+output_conv') for t in big), big
     for o in eng.plan(1, 256, 448)['ops']:
         if o['kind'] == 'conv_mfma' and o['wino'] == 4:
-            assert o['Ctot'] >= 208 or (o['Ctot'] >= 128 and o['Cout'] == 32), o['tag']
-    # the tile knob: a shape every nested layer can run is taken (32-channel Q8 tile = 1); out-of-range values are refused
+            assert o['Ctot'] % 16 == 0 and o['Cout'] % 32 == 0 and o['w2d_off'] >= 0, o['tag']
+    # the tile knob: a shape a nested layer can run is taken (32-channel tile = 1; the layer with the fused RGB head needs all 64
+    # channels of a pixel in one workgroup and keeps tile 0); out-of-range values are refused
     eng.set_option('w2d_shape', 1)
-    tiles = {o['tile'] for o in eng.plan(1, 256, 448)['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4}
-    assert tiles == {1 | 8192 | 16}, tiles
+    tiles = {(o['tile'], '+output_conv' in o['tag']) for o in eng.plan(1, 256, 448)['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4}
+    assert tiles == {(1 | 8192 | 16, False), (0 | 8192 | 16, True)}, tiles
     eng.set_option('w2d_shape', -1)
     with pytest.raises(FilmError):
         eng.set_option('w2d_shape', 99)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "retired/conv_wino2d_r3_impl.h"
+#include "../frame-interpolation_amd/csrc/conv_wino43_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino2d_impl.h"
 
 #define CK(x)                                                                              \
@@ -68,6 +69,20 @@ __global__ void pack_wino2d_kernel(const float* src, float* dst, int C, int N) {
   }
 }
 
+// [tap*C + c][N] -> [N][chunk8][dy][nu 6][8]: F(4,3) weight transform along x (conv_wino43_impl.h)
+__global__ void pack_wino43_kernel(const float* src, float* dst, int C, int N) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)3 * C * N) return;
+  const int n = (int)(i % N);
+  const int c = (int)((i / N) % C), dy = (int)(i / ((size_t)N * C));
+  const float g0 = src[((size_t)(dy * 3 + 0) * C + c) * N + n], g1 = src[((size_t)(dy * 3 + 1) * C + c) * N + n],
+              g2 = src[((size_t)(dy * 3 + 2) * C + c) * N + n];
+  const float u[6] = {g0 * 0.25f, -((g0 + g2) + g1) * (1.f / 6.f), -((g0 + g2) - g1) * (1.f / 6.f),
+                      (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) + g1 * (1.f / 12.f), (g0 * (1.f / 24.f) + g2 * (1.f / 6.f)) - g1 * (1.f / 12.f), g2};
+  for (int nu = 0; nu < 6; ++nu)
+    dst[((((size_t)n * (C / 8) + c / 8) * 3 + dy) * 6 + nu) * 8 + c % 8] = u[nu];
+}
+
 __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* out) {
   float m = 0.f;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
@@ -79,15 +94,19 @@ __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* 
 
 typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
 // fam 0: the bits of round 3's conv_wino2d_r3_kernel (reference = the first variant run); fam 1: conv_wino2d_kernel's own family (reference = the
-// first fam-1 variant run; its distance from family 0 is printed); fam -1: timing ablation (wrong on purpose)
+// first fam-1 variant run; its distance from family 0 is printed); fam -1: timing ablation (wrong on purpose); fam 2: the 1-D F(4,3)
+// kernel conv_wino43_kernel (its own weights and sums: timing reference, distance from family 0 printed)
 struct Variant { const char* name; int bn; int fam; LaunchFn fn; };
 constexpr int SCHED = W2R_F_ILV | W2R_F_LATE | W2R_F_B2;
 constexpr int MIDF = W2R_F_ILV | W2R_F_B2 | W2R_F_MIDBAR;
 #define W2D(NAME, BN, FL) {"r3  " NAME, BN, 0, conv_wino2d_r3_launch<8, BN, FL, 8>}
 #define W2N(NAME, BN, FL) {"w2d " NAME, BN, ((FL) & 0x3F00) ? -1 : ((FL) & W2D_F_XFIRST) ? 0 : 1, conv_wino2d_launch<BN, FL>}
+#define W43(NAME, BN, ...) {"w43 " NAME, BN, 2, conv_wino43_launch<__VA_ARGS__>}
 static Variant variants[] = {
     W2D("8x64_RM", 64, 4 | MIDF | W2R_F_RAW), W2D("8x32_R", 32, 4 | SCHED | W2R_F_RAW), W2D("8x32_M", 32, 4 | MIDF), W2D("8x64_R", 64, 4 | SCHED | W2R_F_RAW),
     W2D("8x64_RM plain", 64, MIDF | W2R_F_RAW), W2D("8x32_R plain", 32, SCHED | W2R_F_RAW),
+    W43("q16 4x64 t21 p2", 64, 4, 64, 2, 1, 4 | W43_F_PF2, 16), W43("q16 4x64 n1 p2", 64, 4, 64, 1, 1, 4 | W43_F_PF2, 16, 1), W43("q8 8x64 t21 p2", 64, 8, 64, 2, 1, 4 | W43_F_PF2, 8),
+    W43("q8 8x64 n1 p2", 64, 8, 64, 1, 1, 4 | W43_F_PF2, 8, 1), W43("q16 4x32 bg", 32, 4, 32, 1, 1, 4 | W43_F_BG, 16), W43("q8 8x32 bg", 32, 8, 32, 1, 1, 4 | W43_F_BG, 8), W43("q8 8x32 p2", 32, 8, 32, 1, 1, 4 | W43_F_PF2, 8),
     W2N("64 xf", 64, 4 | W2D_F_XFIRST), W2N("32 xf", 32, 4 | W2D_F_XFIRST),
     W2N("64", 64, 4), W2N("32", 32, 4), W2N("64 plain", 64, 0), W2N("32 plain", 32, 0),
     W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
@@ -113,6 +132,16 @@ static Shape shapes[] = {
     {"flow_l0_c0  8x576x960  128->32", 8, 576, 960, 128, 32, 0},
     {"fusion_2_2  4x144x240  256->256", 4, 144, 240, 256, 256, 0},
     {"feat_conv7  8x72x120   512->512", 8, 72, 120, 512, 512, 0},
+    {"feat_conv1  8x576x960   64->64", 8, 576, 960, 64, 64, 0},
+    {"feat_conv2  8x288x480   64->128", 8, 288, 480, 64, 128, 0},
+    {"feat_conv3  8x288x480  128->128", 8, 288, 480, 128, 128, 0},
+    {"feat_conv4  8x144x240  128->256", 8, 144, 240, 128, 256, 0},
+    {"feat_conv5  8x144x240  256->256", 8, 144, 240, 256, 256, 0},
+    {"flow_l0_c1  8x576x960   32->32", 8, 576, 960, 32, 32, 0},
+    {"flow_l1_c1  8x288x480   64->64", 8, 288, 480, 64, 64, 0},
+    {"flow_l2_c1  8x144x240  128->128", 8, 144, 240, 128, 128, 0},
+    {"fusion_0_2  4x576x960   64->64", 4, 576, 960, 64, 64, 0},
+    {"fusion_1_2  4x288x480  128->128", 4, 288, 480, 128, 128, 0},
     {"two-seg     4x144x240  (96|48)->64, batch halves swapped in seg 1", 4, 144, 240, 144, 64, 48},
     {"ragged      3x36x60    64->64", 3, 36, 60, 64, 64, 0},
     {"ragged2     2x50x70    (32|16)->32", 2, 50, 70, 48, 32, 16},
@@ -136,11 +165,12 @@ int main(int argc, char** argv) {
     const int C1 = sh.C - sh.C2;
     const int strideA = C1 + 16, strideB = sh.C2 ? sh.C2 + 32 : 0;   // the segments are channel slices of wider buffers
     const size_t n_a = M * strideA, n_b = M * strideB, n_w = (size_t)9 * sh.C * sh.Cout, n_out = M * sh.Cout;
-    float *d_a, *d_bb = nullptr, *d_w, *d_w2d, *d_b, *d_out, *d_ref, *d_ref1, *d_md;
+    float *d_a, *d_bb = nullptr, *d_w, *d_w2d, *d_w43, *d_b, *d_out, *d_ref, *d_ref1, *d_md;
     CK(hipMalloc(&d_a, n_a * 4));
     if (n_b) CK(hipMalloc(&d_bb, n_b * 4));
     CK(hipMalloc(&d_w, n_w * 4));
     CK(hipMalloc(&d_w2d, n_w * 4 * 24 / 9 + 64));
+    CK(hipMalloc(&d_w43, n_w * 4 * 18 / 9 + 64));
     CK(hipMalloc(&d_ref, n_out * 4));
     CK(hipMalloc(&d_ref1, n_out * 4));
     CK(hipMalloc(&d_md, 4));
@@ -150,6 +180,7 @@ int main(int argc, char** argv) {
     if (n_b) hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_bb, n_b, 7u, 1.0f);
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_w, n_w, 2u, 0.05f);
     hipLaunchKernelGGL(fill_kernel, dim3(64), dim3(256), 0, st, d_b, (size_t)sh.Cout, 3u, 0.1f);
+    hipLaunchKernelGGL(pack_wino43_kernel, dim3((unsigned)((n_w / 3 + 255) / 256)), dim3(256), 0, st, d_w, d_w43, sh.C, sh.Cout);
     hipLaunchKernelGGL(pack_wino2d_kernel, dim3((unsigned)((n_w / 9 + 255) / 256)), dim3(256), 0, st, d_w, d_w2d, sh.C, sh.Cout);
     CK(hipStreamSynchronize(st));
     unsigned long long* d_tm;
@@ -178,6 +209,7 @@ int main(int argc, char** argv) {
         if (!hit) continue;
       }
       CK(hipMemsetAsync(d_out, 0xFF, n_out * 4, st));   // NaN: an unwritten output shows
+      p.w = v.fam == 2 ? d_w43 : d_w2d;
       hipError_t le = v.fn(p, st);
       if (le != hipSuccess) { printf("   %-24s  refused (%s)\n", v.name, hipGetErrorString(le)); (void)hipGetLastError(); continue; }
       CK(hipMemsetAsync(d_sum, 0, sizeof(double), st));
@@ -197,7 +229,9 @@ int main(int argc, char** argv) {
       };
       const int fam = v.fam < 0 ? 1 : v.fam;   // (ablations are variants of the y-first loop)
       float* const refs[2] = {d_ref, d_ref1};
-      if (v.fam >= 0 && !have_ref[fam]) {
+      if (v.fam == 2) {
+        if (have_ref[0]) fam_dist = diff_to(d_ref);
+      } else if (v.fam >= 0 && !have_ref[fam]) {
         have_ref[fam] = true;
         CK(hipMemcpyAsync(refs[fam], d_out, n_out * 4, hipMemcpyDeviceToDevice, st));
         CK(hipStreamSynchronize(st));
@@ -231,13 +265,13 @@ int main(int argc, char** argv) {
       const bool abl = v.fam < 0;
       if (!abl && maxdiff != 0.f) ++bad;
       printf("   %-24s  min %8.3f ms  avg %8.3f ms  %7.1f TF/s direct-eq  %s max|d| %.2e", v.name, best, tot / reps, flops / best * 1e-9,
-             abl ? "(ablation)" : maxdiff == 0.f ? (fam ? "bit-identical (family 1)" : "bit-identical (family 0)") : "MISMATCH", maxdiff);
-      if (fam_dist >= 0.f) printf("   [family 1 vs family 0: max|d| %.2e, checksum %.6e]", fam_dist, sum);
+             abl ? "(ablation)" : v.fam == 2 ? "1-D family" : maxdiff == 0.f ? (fam ? "bit-identical (family 1)" : "bit-identical (family 0)") : "MISMATCH", maxdiff);
+      if (fam_dist >= 0.f) printf("   [vs family 0: max|d| %.2e, checksum %.6e]", fam_dist, sum);
       printf("\n");
       fflush(stdout);
     }
     CK(hipFree(d_tm));
-    CK(hipFree(d_a)); if (d_bb) CK(hipFree(d_bb)); CK(hipFree(d_w)); CK(hipFree(d_w2d)); CK(hipFree(d_ref)); CK(hipFree(d_ref1)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
+    CK(hipFree(d_a)); if (d_bb) CK(hipFree(d_bb)); CK(hipFree(d_w)); CK(hipFree(d_w2d)); CK(hipFree(d_w43)); CK(hipFree(d_ref)); CK(hipFree(d_ref1)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   printf("mismatches: %d\n", bad);
   return bad ? 1 : 0;
