@@ -394,10 +394,15 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   float* const orow = p.out + (((size_t)img * p.H + oy) * p.W + ox) * p.ostride + nrd;
   // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
   // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
-  // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][65] behind the exchange
-  // buffers instead of to `out`; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
+  // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][68] behind the exchange
+  // buffers instead of to `out` (68: 16-byte rows whose float4 pieces fall into 16 different bank groups for 16 consecutive pixels -
+  // conflict-free ds_write_b128 from the (unit, channel group) threads and ds_read_b128 from the pixel threads); the 1x1 weights go
+  // to LDS once as [c][4]; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
   float* const pool_base = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.pool_ostride + nrd : nullptr;
+  constexpr int PWS = 68;
   float* const pwt = smem + 2 * XB4 * 4;
+  float* const pww = pwt + TH * PXW * PWS;   // [64][4]
+  if (p.pw_out != nullptr && t < 256) pww[t] = (t & 3) < p.pw_cout ? p.pw_w[(t >> 2) * p.pw_cout + (t & 3)] : 0.f;   // (published by the rounds' barriers)
   bf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int jx = 0; jx < 4; ++jx) {
@@ -435,9 +440,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
         }
       }
     } else {
-      float* const tr = pwt + ((2 * (run >> 3)) * PXW + 4 * (run & 7) + jx) * 65 + rng * 32 + rcg * 4;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { tr[c] = r0[c]; tr[PXW * 65 + c] = r1[c]; }
+      float* const tr = pwt + ((2 * (run >> 3)) * PXW + 4 * (run & 7) + jx) * PWS + rng * 32 + rcg * 4;
+      *reinterpret_cast<bf4*>(tr) = r0;
+      *reinterpret_cast<bf4*>(tr + PXW * PWS) = r1;
     }
   }
   if (p.pw_out != nullptr) {
@@ -445,13 +450,17 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     if (t < TH * PXW) {
       const int y = y0 + t / PXW, x = x0 + (t % PXW);
       float a[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* row = pwt + t * 65;
-#pragma unroll 8
-      for (int c = 0; c < 64; ++c) {
-        const float v = row[c];
+      const bf4* row = reinterpret_cast<const bf4*>(pwt + t * PWS);
+      const bf4* wq = reinterpret_cast<const bf4*>(pww);
+#pragma unroll 4
+      for (int c4 = 0; c4 < 16; ++c4) {
+        const bf4 v = row[c4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < p.pw_cout) a[j] = __builtin_fmaf(v, p.pw_w[c * p.pw_cout + j], a[j]);
+        for (int k = 0; k < 4; ++k) {
+          const bf4 w = wq[c4 * 4 + k];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[j] = __builtin_fmaf(v[k], w[j], a[j]);   // (columns past pw_cout: zero weights, never stored)
+        }
       }
       if (y < p.H && x < p.W) {
         float* dd = p.pw_out + (((size_t)img * p.H + y) * p.W + x) * p.pw_ostride;
@@ -472,8 +481,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 
 template <int BN, int FLAGS>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
-  // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside; the fused 1x1 adds its [256][65] tile behind them
-  const size_t lds = p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 65 * 4 : (size_t)3 * 24 * 1024;
+  // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside; the fused 1x1 adds its [256][68] tile and its weights behind them
+  const size_t lds = p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024 : (size_t)3 * 24 * 1024;
   constexpr int NT = 4 * (BN / 32) * 64;
   if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 16 || p.Cout % BN) return hipErrorInvalidValue;
   if (p.pw_out) {   // a workgroup must hold every channel of its pixels
