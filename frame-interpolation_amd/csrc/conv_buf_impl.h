@@ -243,7 +243,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
         for (int mt = 0; mt < TM; ++mt)
 #pragma unroll
           for (int nt = 0; nt < TN; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kq][mt][j], b[kq][nt][j], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[kq][nt][j], a[kq][mt][j], acc[mt][nt], 0, 0, 0);   // A = weights: C^T, the same sums
   };
 
   // ---- two-step prefetch pipeline (see conv_igemm_impl.h for the reasoning behind the shape of this loop) --
@@ -268,34 +268,38 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias + leaky_relu, 128-B row stores ---------------------------------------------
-  // C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+  // ---- epilogue: bias + leaky_relu.  The MFMA ran with A = weights, B = pixels: C/D column = lane & 31 = pixel row of the tile,
+  // row = (r&3) + 8*(r>>2) + 4*(lane>>5) = output channel - a lane holds four CONSECUTIVE channels of its pixel per register group:
+  // four dwordx4 stores per 32x32 tile instead of sixteen dword stores (round 4: the store count, not the bytes, was the cost).
 #pragma unroll
-  for (int nt = 0; nt < TN; ++nt) {
-    const int n = n0 + wn * WTN + nt * 32 + l31;
-    const float bv = p.bias[n];
-#pragma unroll
-    for (int mt = 0; mt < TM; ++mt) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = m0 + wm * WTM + mt * 32 + row;
-        if (m < p.M) {
-          if (ksplit > 1) {  // raw partial sum; bias + activation in conv_splitk_reduce_kernel
-            p.part[((size_t)split * p.M + m) * p.Cout + n] = acc[mt][nt][r];
-            continue;
-          }
-          float v = acc[mt][nt][r] + bv;
-          if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-          size_t opix = (size_t)m;
-          if (p.fold) {  // low-resolution pixel (b, y, x) -> output pixel (b, 2y+py, 2x+px) of the 2H x 2W image
-            const int b = m / HW, rr = m - b * HW, y = rr / p.W, x = rr - y * p.W;
-            opix = ((size_t)b * 2 * p.H + 2 * y + fpy) * (2 * p.W) + 2 * x + fpx;
-          }
-          p.out[opix * p.ostride + n] = v;
-        }
-      }
+  for (int mt = 0; mt < TM; ++mt) {
+    const int m = m0 + wm * WTM + mt * 32 + l31;
+    if (m >= p.M) continue;
+    size_t opix = (size_t)m;
+    if (p.fold) {  // low-resolution pixel (b, y, x) -> output pixel (b, 2y+py, 2x+px) of the 2H x 2W image
+      const int bq = m / HW, rr = m - bq * HW, y = rr / p.W, x = rr - y * p.W;
+      opix = ((size_t)bq * 2 * p.H + 2 * y + fpy) * (2 * p.W) + 2 * x + fpx;
     }
+#pragma unroll
+    for (int nt = 0; nt < TN; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = n0 + wn * WTN + nt * 32 + 8 * g + 4 * half;
+        bf4 v;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = acc[mt][nt][4 * g + c];
+        if (ksplit > 1) {  // raw partial sums; bias + activation in conv_splitk_reduce_kernel
+          *reinterpret_cast<bf4*>(p.part + ((size_t)split * p.M + m) * p.Cout + n) = v;
+          continue;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float u = v[c] + p.bias[n + c];
+          if (p.leaky) u = u > 0.f ? u : 0.2f * u;
+          v[c] = u;
+        }
+        *reinterpret_cast<bf4*>(p.out + opix * p.ostride + n) = v;
+      }
   }
 }
 
@@ -314,6 +318,7 @@ hipError_t conv_buf_launch(const ConvParams& p, hipStream_t s) {
     }
   }
   if (p.ksplit > 1 && p.fold) return hipErrorInvalidValue;
+  if (p.ksplit > 1 ? (p.Cout % 4 || (reinterpret_cast<uintptr_t>(p.part) & 15)) : (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15))) return hipErrorInvalidValue;   // dwordx4 stores
   dim3 grid((p.M + BM - 1) / BM, p.Cout / BN, p.fold == 2 ? 4 : (p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(WGM * WGN * 64), lds, s, p);
   return hipGetLastError();

@@ -238,10 +238,14 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 #pragma unroll
     for (int j = 0; j < 6; ++j) fbg[set][j] = conv_buf_load(brsrc, bvoff, slab(set) + (unsigned)j * 1024u);
   __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // this wave's share of stage 0 (older than the twelve weight requests)
-  __syncthreads();
+  // super-chunks 1 and 2 go out before anybody waits (their latency runs beside stage 0's); this wave's share of stage 0 is older
+  // than the twelve weight requests and these
   if (nsc > 1) raw_issue(1);
   if (nsc > 2) raw_issue(2);
+  if (nsc > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + 2 * IPW) : "memory");
+  else if (nsc > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + IPW) : "memory");
+  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __syncthreads();
   prepare(A[0], 0, C0{});
 
   // ---- K loop: chunk kc = (super-chunk s, half h).  Super-chunk s lives in stage s % 3; chunk kc prepares the fragments of chunk
