@@ -255,6 +255,7 @@ def main():
                     help='experiment: multiply the last 1x1 layer of every flow predictor (kernel and bias) by this (0 = zero flows: every warp '
                          'is the identity, the smoothest possible gather; 1 = the seeded synthetic weights)')
     ap.add_argument('--fuse', type=int, default=None, help='engine option "fuse" (bit mask, default 31)')
+    ap.add_argument('--opt', action='append', default=[], metavar='KEY=VALUE', help='extra engine option (film_set_option), repeatable - A/B experiments')
     ap.add_argument('--wino2d', type=int, default=None, choices=[0, 1, 2], help='engine option "wino2d" (nested Winograd kernel); default: the engine default')
     ap.add_argument('--no-split', action='store_true', help='skip the extra bf16x6 / bf16x3 precision-mode measurements')
     ap.add_argument('--profile-out', default='', help='write the per-op profile JSON here')
@@ -322,6 +323,9 @@ def main():
         eng.set_option('wino2d', args.wino2d)
     if args.fuse is not None:
         eng.set_option('fuse', args.fuse)
+    for kv in args.opt:
+        k, v = kv.split('=')
+        eng.set_option(k, int(v))
     if args.precision:
         eng.set_option('precision', args.precision)
         args.no_split = True

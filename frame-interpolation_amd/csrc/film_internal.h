@@ -190,6 +190,8 @@ struct film_handle {
   hipStream_t stream2 = nullptr;
   int opt_precision = 0;  // 0: fp32 MFMA everywhere (default); 1: bf16x6 exact-split MFMA for the large 3x3 convs; 2: bf16x3
   int opt_wino2d = 1;     // nested Winograd kernel: 0 never, 1 (default) the deep-K layers of the large levels, 2 every layer that has the copy (tests)
+  int opt_w2d_min_px = 1536; // conv_wino2d_kernel runs the 3x3 layers of levels with at least this many pixels per image (planner rule;
+                             // profiles/r04_w2d_min_px_ab.log: 8 or more 8x32 patches per image - 32x56 yes, 32x32 no)
   int opt_w2d_shape = -1; // tests: >= 0 = every conv_wino2d_kernel op that can run this Wino2dTile shape does
   int opt_w43_shape = -1; // tests: >= 0 = every conv_wino43_kernel op that can run this Wino43Tile shape does (instead of the autotuned one)
   std::string profile_json;

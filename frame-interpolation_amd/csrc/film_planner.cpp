@@ -156,18 +156,17 @@ struct Planner {
     // fills its 64-pixel patches (the Q16 tiles; at most 15 % of the last patch of a row empty: 960 ... 60, 448, 256 ...); wino = 3.  "winograd" = 2 / 3 force
     // F(2,3) / F(4,3) onto every eligible layer (tests).
     if (op.wino == 1 && h->opt_wino != 2 && w43_width) op.wino = 3;
-    // Nested F(4,3)x x F(2,3)y (conv_wino2d_kernel, 1.5x fewer MFMAs again): the deep-K layers (K >= 384: the first layer of
-    // every flow predictor but level 0's, the wide layer of every decoder level but level 0's, cfeat_conv_7) on levels large
-    // enough to fill the chip without split-K.  A family of its own (a function of the layer and the level size only).
-    // (Round 3, second half: no longer tied to the 1-D kernel's own thresholds - a 64-channel layer needed 30 000 pixels for those,
-    // which left K = 384 -> 64 of flow level 1 on the direct kernel for 448x256 and 256x256 frames.)
+    // Nested F(4,3)x x F(2,3)y (conv_wino2d_kernel, 1.5x fewer MFMAs than the 1-D form): round 4 - EVERY 3x3 layer whose channels come
+    // in sixteens (K = 32 ... 2448) on levels of at least opt_w2d_min_px pixels per image (default 1536: eight or more of its 8x32
+    // patches per image; below that the 1-D kernel's split-K fills the chip better at batch 1).  A family of its own, a function of the
+    // layer and the level size only.  A/B over the BASELINE configs: profiles/r04_w2d_min_px_ab.log.
     // conv_wino2d_kernel moves the halo patch by DMA in 16-channel pieces and stores four channels per lane: every input segment
     // a multiple of 16 channels at 16-byte aligned pixels, a 16-byte aligned output slice (true of every such layer of the
     // published net; a property of the layer's buffers, so still a function of the layer only)
     bool w2d_layout = ctot % 16 == 0 && out.off % 4 == 0 && out.stride % 4 == 0;
     for (int i = 0; i < op.nseg; ++i) w2d_layout = w2d_layout && segs[i].v.C % 16 == 0 && segs[i].v.off % 4 == 0 && segs[i].v.stride % 4 == 0;
     if (L.w2d_off >= 0 && w2d_layout && !any_up && h->opt_precision == 0 && op.split == 0 &&
-        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= 8192)))
+        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= h->opt_w2d_min_px)))
       op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
