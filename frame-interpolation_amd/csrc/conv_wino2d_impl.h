@@ -166,7 +166,11 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int ra = mu == 0 ? 0 : mu == 2 ? 2 : 1, rb = mu == 0 ? 2 : mu == 1 ? 2 : mu == 2 ? 1 : 3;
   const float sgn = mu == 1 ? 1.f : -1.f;
   const int ix_a = (2 * ur + ra) * RP4 + half * CO4 + lq, ix_b = (2 * ur + rb) * RP4 + half * CO4 + lq;
-  float A[2][6][4];   // A[kc & 1]: the fragments of chunk kc (all six nu planes, this lane's four channels)
+  // PACKED fp32 math for both transforms (tools/experiments/mfma_valu_overlap.hip: a VALU instruction between two fp32 MFMAs costs
+  // ~4 cycles of matrix-pipe time - the f32 MFMA and the VALU share the SIMD - and v_pk_fma_f32 costs what v_fma_f32 costs for
+  // twice the work): a lane's four channels are two float2, 36 instructions per chunk instead of 72.  Same operations per element.
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 A[2][6][2];      // A[kc & 1]: the fragments of chunk kc (all six nu planes, this lane's four channels as two pairs)
   bf4 d[6];           // raw pixels of row a (then: of the combined row)
   bf4 d2[6];          // raw pixels of row b
 
@@ -178,54 +182,66 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 #pragma unroll
     for (int j = 0; j < 6; ++j) dst[j] = smem4[ixs + IMM + (j & 3) * MO4 + (j >> 2)];
   };
-  // F(4,3) B^T of channel c of the six pixels in d: 12 operations (v3 / v4 = t3 +- 2 (d3 - d1): the doubling is exact, so
-  // fma(+-2, d3 - d1, t3) rounds the very sum conv_wino2d_r3_kernel formed with a multiplication and an addition)
-  float xt[4];
-  auto xf_t = [&](int c) {
-    const float d1 = d[1][c], d2v = d[2][c], d3 = d[3][c], d4 = d[4][c];
-    xt[0] = __builtin_fmaf(-4.f, d2v, d4);
-    xt[1] = __builtin_fmaf(-4.f, d1, d3);
-    xt[2] = d4 - d2v;
-    xt[3] = d3 - d1;
+  auto pair_of = [](const bf4& v, int q) -> f2 { return q ? f2{v[2], v[3]} : f2{v[0], v[1]}; };
+  auto set_pair = [](bf4& v, int q, f2 x) { if (q) { v[2] = x[0]; v[3] = x[1]; } else { v[0] = x[0]; v[1] = x[1]; } };
+  // (hipcc scalarises a <2 x float> fma / add written in C here - 72 v_fma_f32 again - so the packed instructions are spelled out;
+  // plain `asm`, not volatile: they are pure functions of their operands and the compiler schedules them like any other)
+  auto fma2 = [](float k, f2 x, f2 y) -> f2 {
+    f2 r;
+    const f2 kk = {k, k};
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "s"(kk), "v"(x), "v"(y));
+    return r;
   };
-  auto xf_v = [&](int c, int nu) -> float {
-    if constexpr ((FLAGS & W2D_DBG_NOXF) != 0) return d[nu][c];
+  auto add2 = [](f2 x, f2 y) -> f2 { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto sub2 = [](f2 x, f2 y) -> f2 { f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  // F(4,3) B^T of channel pair q of the six pixels in d: 12 operations (v3 / v4 = t3 +- 2 (d3 - d1): the doubling is exact, so
+  // fma(+-2, d3 - d1, t3) rounds the very sum conv_wino2d_r3_kernel formed with a multiplication and an addition)
+  f2 xt[4];
+  auto xf_t = [&](int q) {
+    const f2 d1 = pair_of(d[1], q), d2v = pair_of(d[2], q), d3 = pair_of(d[3], q), d4 = pair_of(d[4], q);
+    xt[0] = fma2(-4.f, d2v, d4);
+    xt[1] = fma2(-4.f, d1, d3);
+    xt[2] = sub2(d4, d2v);
+    xt[3] = sub2(d3, d1);
+  };
+  auto xf_v = [&](int q, int nu) -> f2 {
+    if constexpr ((FLAGS & W2D_DBG_NOXF) != 0) return pair_of(d[nu], q);
     switch (nu) {
-      case 0: return __builtin_fmaf(4.f, d[0][c], __builtin_fmaf(-5.f, d[2][c], d[4][c]));
-      case 1: return xt[0] + xt[1];
-      case 2: return xt[0] - xt[1];
-      case 3: return __builtin_fmaf(2.f, xt[3], xt[2]);
-      case 4: return __builtin_fmaf(-2.f, xt[3], xt[2]);
-      default: return __builtin_fmaf(4.f, d[1][c], __builtin_fmaf(-5.f, d[3][c], d[5][c]));
+      case 0: return fma2(4.f, pair_of(d[0], q), fma2(-5.f, pair_of(d[2], q), pair_of(d[4], q)));
+      case 1: return add2(xt[0], xt[1]);
+      case 2: return sub2(xt[0], xt[1]);
+      case 3: return fma2(2.f, xt[3], xt[2]);
+      case 4: return fma2(-2.f, xt[3], xt[2]);
+      default: return fma2(4.f, pair_of(d[1], q), fma2(-5.f, pair_of(d[3], q), pair_of(d[5], q)));
     }
   };
   // hipcc sinks a value whose only readers sit behind the next branch (the next chunk) out of the MFMA gap it was written in -
   // down to one block of VALU instructions in front of the chunk that needs them: an empty statement "using" it pins it
-  auto pin = [](float& v) { asm volatile("" : "+v"(v)); };
+  auto pin = [](f2& v) { asm volatile("" : "+v"(v)); };
   // the whole preparation of a chunk's fragments in one go (prologue only)
-  auto prepare = [&](float (&An)[6][4], int stage, auto h_c) {
+  auto prepare = [&](f2 (&An)[6][2], int stage, auto h_c) {
     read_row(d, ix_a, stage, h_c);
     read_row(d2, ix_b, stage, h_c);
     if constexpr (!XF) {
 #pragma unroll
       for (int j = 0; j < 6; ++j)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) d[j][c] = __builtin_fmaf(sgn, d2[j][c], d[j][c]);
+        for (int q = 0; q < 2; ++q) set_pair(d[j], q, fma2(sgn, pair_of(d2[j], q), pair_of(d[j], q)));
     }
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      xf_t(c);
+    for (int q = 0; q < 2; ++q) {
+      xf_t(q);
 #pragma unroll
-      for (int nu = 0; nu < 6; ++nu) An[nu][c] = xf_v(c, nu);
+      for (int nu = 0; nu < 6; ++nu) An[nu][q] = xf_v(q, nu);
     }
     if constexpr (XF) {
 #pragma unroll
       for (int j = 0; j < 6; ++j) d[j] = d2[j];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        xf_t(c);
+      for (int q = 0; q < 2; ++q) {
+        xf_t(q);
 #pragma unroll
-        for (int nu = 0; nu < 6; ++nu) An[nu][c] = __builtin_fmaf(sgn, xf_v(c, nu), An[nu][c]);
+        for (int nu = 0; nu < 6; ++nu) An[nu][q] = fma2(sgn, xf_v(q, nu), An[nu][q]);
       }
     }
   };
@@ -260,8 +276,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     constexpr int H = decltype(h_c)::value;
     using RH = std::integral_constant<int, 1 - H>;
     const int rs = H == 0 ? st_s : st_n;   // stage of chunk kc + 1
-    float(&Ac)[6][4] = A[H];
-    float(&An)[6][4] = A[1 - H];
+    f2(&Ac)[6][2] = A[H];
+    f2(&An)[6][2] = A[1 - H];
     if constexpr (H == 1) {
       // This wave's requests for super-chunk s + 1 are older than the weight requests of the last chunks (in-order return): the last
       // one went out in a gap of chunk kc - 3, at least 14 weight requests ago (s + 1 < 3: in the prologue, behind it DMA requests
@@ -281,7 +297,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       constexpr int g = decltype(g_c)::value;
       constexpr int jp = g >> 3, i8 = g & 7, k = i8 >> 1, j = 2 * jp + (i8 & 1);
       // A = weights (row = output channel), B = activations (column = unit): C^T of conv_wino2d_r3_kernel's tile, the same k-ordered sums
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k], acc[j], 0, 0, 0);
+      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k >> 1][k & 1], acc[j], 0, 0, 0);
       if constexpr ((FLAGS & W2D_DBG_NOB) == 0) {
         if constexpr (k == 3) fbg[H][j] = conv_buf_load(brsrc, bvoff, so2 + (unsigned)j * 1024u);   // consumed: chunk kc + 2's slab into the same registers
       }
@@ -291,56 +307,52 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
         if constexpr (XF && g == 10) read_row(d, ix_b, rs, RH{});
       }
       if constexpr (!XF) {
-        if constexpr (g >= 4 && g < 10) {   // y combine of pixel g - 4
+        if constexpr (g >= 4 && g < 10) {   // y combine of pixel g - 4: two packed operations
           constexpr int jj = g - 4;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) { float v = __builtin_fmaf(sgn, d2[jj][c], d[jj][c]); pin(v); d[jj][c] = v; }
+          for (int q = 0; q < 2; ++q) { f2 v = fma2(sgn, pair_of(d2[jj], q), pair_of(d[jj], q)); pin(v); set_pair(d[jj], q, v); }
         }
-        if constexpr (g >= 10 && g < 22) {   // x transform: channel (g - 10) / 3 in three parts
-          constexpr int c = (g - 10) / 3, part = (g - 10) % 3;
+        if constexpr (g >= 10 && g < 16) {   // x transform: channel pair (g - 10) / 3 in three parts of four packed operations
+          constexpr int q = (g - 10) / 3, part = (g - 10) % 3;
           if constexpr (part == 0) {
-            xf_t(c);
-            An[0][c] = xf_v(c, 0);
-            An[5][c] = xf_v(c, 5);
-            pin(An[0][c]); pin(An[5][c]); pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+            xf_t(q);
+            pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
           } else if constexpr (part == 1) {
-            An[1][c] = xf_v(c, 1);
-            An[2][c] = xf_v(c, 2);
-            pin(An[1][c]); pin(An[2][c]);
+            An[0][q] = xf_v(q, 0);
+            An[5][q] = xf_v(q, 5);
+            pin(An[0][q]); pin(An[5][q]);
           } else {
-            An[3][c] = xf_v(c, 3);
-            An[4][c] = xf_v(c, 4);
-            pin(An[3][c]); pin(An[4][c]);
+#pragma unroll
+            for (int nu = 1; nu < 5; ++nu) { An[nu][q] = xf_v(q, nu); pin(An[nu][q]); }
           }
         }
       } else {
-        if constexpr (g >= 2 && g < 10) {          // row a: channel (g - 2) / 2, first / second half of its operations
-          constexpr int c = (g - 2) >> 1;
-          if constexpr (((g - 2) & 1) == 0) {
-            xf_t(c);
-            An[0][c] = xf_v(c, 0);
-            An[5][c] = xf_v(c, 5);
-            pin(An[0][c]); pin(An[5][c]); pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+        if constexpr (g >= 2 && g < 8) {           // row a: channel pair (g - 2) / 3 in three parts
+          constexpr int q = (g - 2) / 3, part = (g - 2) % 3;
+          if constexpr (part == 0) {
+            xf_t(q);
+            pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+          } else if constexpr (part == 1) {
+            An[0][q] = xf_v(q, 0);
+            An[5][q] = xf_v(q, 5);
+            pin(An[0][q]); pin(An[5][q]);
           } else {
 #pragma unroll
-            for (int nu = 1; nu < 5; ++nu) { An[nu][c] = xf_v(c, nu); pin(An[nu][c]); }
+            for (int nu = 1; nu < 5; ++nu) { An[nu][q] = xf_v(q, nu); pin(An[nu][q]); }
           }
         }
-        if constexpr (g >= 12) {                   // row b + y combine: channel (g - 12) / 3 in three parts
-          constexpr int c = (g - 12) / 3, part = (g - 12) % 3;
+        if constexpr (g >= 12 && g < 18) {         // row b + y combine
+          constexpr int q = (g - 12) / 3, part = (g - 12) % 3;
           if constexpr (part == 0) {
-            xf_t(c);
-            An[0][c] = __builtin_fmaf(sgn, xf_v(c, 0), An[0][c]);
-            An[5][c] = __builtin_fmaf(sgn, xf_v(c, 5), An[5][c]);
-            pin(An[0][c]); pin(An[5][c]); pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
+            xf_t(q);
+            pin(xt[0]); pin(xt[1]); pin(xt[2]); pin(xt[3]);
           } else if constexpr (part == 1) {
-            An[1][c] = __builtin_fmaf(sgn, xf_v(c, 1), An[1][c]);
-            An[2][c] = __builtin_fmaf(sgn, xf_v(c, 2), An[2][c]);
-            pin(An[1][c]); pin(An[2][c]);
+            An[0][q] = fma2(sgn, xf_v(q, 0), An[0][q]);
+            An[5][q] = fma2(sgn, xf_v(q, 5), An[5][q]);
+            pin(An[0][q]); pin(An[5][q]);
           } else {
-            An[3][c] = __builtin_fmaf(sgn, xf_v(c, 3), An[3][c]);
-            An[4][c] = __builtin_fmaf(sgn, xf_v(c, 4), An[4][c]);
-            pin(An[3][c]); pin(An[4][c]);
+#pragma unroll
+            for (int nu = 1; nu < 5; ++nu) { An[nu][q] = fma2(sgn, xf_v(q, nu), An[nu][q]); pin(An[nu][q]); }
           }
         }
       }
