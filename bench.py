@@ -90,6 +90,60 @@ def synth_pair(h, w, seed):
     return x0[None], x1[None].astype(np.float32)
 
 
+def cli_files_workload(eng, args):
+    """`--workload cli_1080p_T3` (SURVEY 8(d) "end to end", reference eval/interpolator_cli.py:152-177): two synthetic 1080p PNGs in a
+    temporary directory -> `--times_to_interpolate 3 --align 64 --block_height 2 --block_width 2` -> nine PNGs, files to files,
+    decode / H2D / recursion / quantise / D2H / encode all inside the timed region.  Timed twice: the device pipeline the CLI uses
+    (eval.util.interpolate_pairs_to_files) and the round-3 path (float32 frames back in one blocking copy, host to_uint8, PNGs one
+    after the other on one thread); the files of the two runs are compared byte for byte."""
+    import filecmp
+    import shutil
+    import tempfile
+    from eval import interpolator as interpolator_lib
+    from eval import interpolator_cli as cli
+    from eval import util
+    T, H, Wd = 3, 1080, 1920
+    tmp = tempfile.mkdtemp(prefix='film_cli_bench_')
+    try:
+        x0, x1 = synth_pair(H, Wd, 5)
+        for name, x in (('in_000.png', x0[0]), ('in_001.png', x1[0])):
+            util.write_image(os.path.join(tmp, name), np.clip(x, 0, 1))
+        it = interpolator_lib.Interpolator('', 64, [2, 2], engine=eng)
+        inputs = cli.list_input_frames(tmp)
+        new_dir, old_dir = os.path.join(tmp, 'new'), os.path.join(tmp, 'old')
+        ms_new, ms_old = [], []
+        for rep in range(args.warmup + args.steps):
+            cli.output_frames([], new_dir)
+            t0 = time.perf_counter()
+            n_new, _ = util.interpolate_pairs_to_files(inputs, 0, 1, 1, T, it, new_dir)
+            if rep >= args.warmup:
+                ms_new.append((time.perf_counter() - t0) * 1e3)
+        for rep in range(1 + min(args.steps, 3)):
+            t0 = time.perf_counter()
+            frames = list(util.interpolate_recursively_from_files(inputs, T, it))
+            cli.output_frames(frames, old_dir)
+            if rep >= 1:
+                ms_old.append((time.perf_counter() - t0) * 1e3)
+        same = all(filecmp.cmp(os.path.join(new_dir, f), os.path.join(old_dir, f), shallow=False) for f in sorted(os.listdir(old_dir)))
+        n_files = len(os.listdir(new_dir))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    gen = 2 ** T - 1
+    ms = float(np.median(ms_new))
+    return {
+        'metric': 'interpolated frames/sec @1080p, files to files (interpolator_cli, times_to_interpolate 3)', 'value': round(gen / (ms * 1e-3), 4),
+        'unit': 'frames/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'cli_1080p_T3: two 1920x1080 PNGs -> align 64, block_shape [2, 2], times_to_interpolate 3 -> 9 PNGs (7 generated); '
+                               'PNG decode, H2D, 7 tiled forwards, device to_uint8, D2H, PNG encode all timed',
+                   'files_written': n_files, 'frames_generated': gen, 'host_threads': os.cpu_count()},
+        'round3_path': {'ms_per_step': round(float(np.median(ms_old)), 3), 'frames_per_s': round(gen / (float(np.median(ms_old)) * 1e-3), 4),
+                        'what': 'float32 frames back in one blocking copy, host to_uint8, serial PIL PNG encode'},
+        'speedup_vs_round3_path': round(float(np.median(ms_old)) / ms, 3),
+        'files_byte_identical_to_round3_path': bool(same),
+    }
+
+
 def cpu_baseline(weights):
     """Times the oracle on the host cores on ONE real tile of the headline workload: a 960x576 pair of the
     published net (2.348 TFLOP of convolutions + the 22 gather warps), no scaling by FLOP ratios.  The
@@ -177,6 +231,8 @@ def plan_only_run(args, world, rank):
         eng.set_weights(W.make_synthetic_weights(opt, seed=0))
     if world > 1:
         broadcast_weights(eng, dist, src=0)
+        from film_hip.sharding import share_tune
+        share_tune(eng, dist, src=0)       # (plan-only handles measure nothing: the header line travels)
     H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
     T = RECURSIONS.get(args.workload, 1)
     b, e = shard_range(args.pairs, world, rank)
@@ -239,7 +295,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=None, help='default 10 (2 for 4k_4x4_T6: a step is 1008 tile-forwards)')
     ap.add_argument('--warmup', type=int, default=None, help='default 3 (1 for 4k_4x4_T6)')
-    ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS))
+    ap.add_argument('--workload', default='1080p_2x2', choices=sorted(WORKLOADS) + ['cli_1080p_T3'])
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'],
                     help='weak (default): every rank interpolates its own frame pairs; strong: ONE pair, its tiles sharded over '
                          'the ranks for the whole recursion tree, generated tiles gathered to rank 0 inside the timed region')
@@ -309,10 +365,15 @@ def main():
                 if k.startswith('predict_flow') and '/conv_4/' in k:
                     weights[k] = (weights[k] * np.float32(args.flow_scale)).astype(np.float32)
         eng.set_weights(weights)
+    bcast_ms = None
     if world > 1:
         # one-time RCCL broadcast of the packed weight blob (137.7 MB) from rank 0
         from film_hip.sharding import broadcast_weights
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
         broadcast_weights(eng, dist, src=0, device=dev)
+        torch.cuda.synchronize()
+        bcast_ms = (time.perf_counter() - tb0) * 1e3
     if os.environ.get('FILM_TUNE_MS'):
         eng.set_option('tune_ms', int(os.environ['FILM_TUNE_MS']))
     if args.no_graph:
@@ -330,6 +391,11 @@ def main():
         eng.set_option('precision', args.precision)
         args.no_split = True
 
+    if args.workload == 'cli_1080p_T3':
+        if world != 1:
+            raise SystemExit('bench.py: cli_1080p_T3 is a one-GPU workload')
+        print(json.dumps(cli_files_workload(eng, args)))
+        return
     H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
     T = RECURSIONS.get(args.workload, 1)
     strong = args.scaling == 'strong'
@@ -354,6 +420,15 @@ def main():
         step = lambda: it(x0, x1)                                                    # noqa: E731
 
     out = None
+    if world > 1:
+        # ONE autotune for the job: rank 0 builds + measures its plans with a first step while the others wait, then every rank
+        # imports rank 0's tile choices (text, film_export_tune) - eight ranks would otherwise each time every candidate, with
+        # 8 x 32 weight-packing threads on the same host cores, and could end up with different tiles (same results, different speed)
+        from film_hip.sharding import share_tune
+        if rank == 0:
+            out = step()
+            torch.cuda.synchronize()
+        share_tune(eng, dist, src=0)
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -369,7 +444,12 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     reported = 1
+    rank_ms = None
     if dist is not None:
+        mine = torch.tensor([dt], dtype=torch.float64, device=dev)
+        every = [torch.zeros(1, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(every, mine)
+        rank_ms = [round(float(v.item()) / args.steps * 1e3, 3) for v in every]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -450,7 +530,7 @@ def main():
         peak = {0: PEAK_FP32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS / 6, 2: PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
         roofline = {
             'bound': 'mfma',
-            'kernel': ('conv class = conv_wino2d_kernel / conv_wino43_kernel / conv_buf_kernel / conv_c3_kernel (fp32 v_mfma_f32_32x32x2_f32); '
+            'kernel': ('conv class = conv_wino2d_kernel (every 3x3 layer of the levels >= 1536 pixels: 91 % of the FLOPs) / conv_buf_kernel / conv_c3_kernel (fp32 v_mfma_f32_32x32x2_f32); '
                        '`achieved` / `frac` count the FLOPs the matrix pipe executes (nested Winograd F(4,3)x x F(2,3)y layers x1/3, F(4,3) x1/2, F(2,3) x2/3, folded 2x2 layers x9/16 '
                        'of the direct convolution)')
                       if not args.precision else
@@ -485,6 +565,18 @@ def main():
                                           'peak because Winograd / the sub-pixel fold execute fewer multiplies - an algorithmic saving, not a utilisation'},
         }
         roofline['dominant_kernel'] = roofline['kernels'][0] if roofline.get('kernels') else None
+        if roofline['dominant_kernel'] is not None and not args.precision:
+            # the dominant kernel by K depth: its prologue / epilogue are a fixed cost per workgroup (s_memtime: 10-19k + 7-9k cycles
+            # against 1.5k per K chunk of eight channels), so the short-K layers pull the kernel's average down
+            ktot = {o['tag']: o['Ctot'] for o in eng.plan(prof['B'], prof['H'], prof['W'])['ops'] if o['kind'] == 'conv_mfma'}
+            classes = []
+            for lo, hi in ((0, 64), (65, 128), (129, 256), (257, 528), (529, 100000)):
+                sel = [o for o in prof['ops'] if o['kind'] == 'conv_mfma' and (o['tile'] & 8192) and lo <= ktot.get(o['tag'], -1) <= hi]
+                if sel:
+                    ms_c = sum(o['ms'] for o in sel)
+                    classes.append({'K': f'{lo}..{hi}' if hi < 100000 else f'{lo}..', 'launches': len(sel), 'ms': round(ms_c, 3),
+                                    'frac': round(sum(o['flops'] for o in sel) / 3.0 / max(ms_c, 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4)})
+            roofline['dominant_kernel']['by_input_channels'] = classes
         extra = {}
         if 'warp' in cls:
             wgbs = cls['warp']['bytes'] / (cls['warp']['ms'] * 1e-3) / 1e9
@@ -495,6 +587,26 @@ def main():
                 'algorithmic_bytes_per_step': cls['warp']['bytes'],
             }
         extra['kernel_ms_per_step'] = {k: round(v['ms'], 3) for k, v in cls.items()}
+        if world == 1 and T == 1 and not strong:
+            # the same step through the drop-in boundary with HOST buffers (numpy in, numpy out: film_interpolate with
+            # FILM_MEM_HOST copies the two frames up and the result down inside the call) - never `value`
+            x0h, x1h = x0.cpu().numpy(), x1.cpu().numpy()
+            host_call = lambda: eng.interpolate_frames(x0h, x1h, align=align, block_shape=block) if pairs == 1 else eng.interpolate_frames(x0h, x1h, align=align)   # noqa: E731
+            host_call()
+            t_h = []
+            for _ in range(5):
+                th0 = time.perf_counter()
+                host_call()
+                t_h.append((time.perf_counter() - th0) * 1e3)
+            pin_in, pin_out = torch.empty(x0.shape, dtype=torch.float32, pin_memory=True), torch.empty(x0.shape, dtype=torch.float32, pin_memory=True)
+            torch.cuda.synchronize()
+            th0 = time.perf_counter(); x0.copy_(pin_in); x1.copy_(pin_in); torch.cuda.synchronize(); h2d = (time.perf_counter() - th0) * 1e3   # noqa: E702
+            th0 = time.perf_counter(); pin_out.copy_(out if out is not None else x0); torch.cuda.synchronize(); d2h = (time.perf_counter() - th0) * 1e3   # noqa: E702
+            hm = float(np.median(t_h))
+            extra['host_buffers'] = {'ms_per_step': round(hm, 3), 'frames_per_s': round(frames_per_step / (hm * 1e-3), 4),
+                                     'h2d_ms': round(h2d, 3), 'd2h_ms': round(d2h, 3), 'bytes_in': int(2 * x0h.nbytes), 'bytes_out': int(x0h.nbytes),
+                                     'note': 'numpy -> numpy through film_interpolate(FILM_MEM_HOST), pageable host memory; h2d / d2h: the same bytes '
+                                             'from / to pinned memory on their own; the headline `value` keeps the frames resident in HBM'}
         value = (1 if strong else reported) * args.steps * frames_per_step / dt
         result = {
             'metric': METRIC.get(args.workload, 'interpolated frames/sec @1080p'), 'value': round(value, 4), 'unit': 'frames/s',
@@ -518,6 +630,12 @@ def main():
         result.update(extra)
         if ms_per_depth is not None:
             result['ms_per_depth'] = ms_per_depth
+        if dist is not None:   # first contact with N > 1 ranks: what the job looked like from the inside
+            result['ranks'] = {'communicator_size': dist.get_world_size(), 'backend': dist.get_backend(), 'ms_per_step_by_rank': rank_ms,
+                               'ms_per_step_min': min(rank_ms), 'ms_per_step_max': max(rank_ms),
+                               'weight_broadcast_ms': None if bcast_ms is None else round(bcast_ms, 2),
+                               'gather_ms_per_step': (round(drv.gather_ms / max(1, drv.runs), 3) if strong and hasattr(drv, 'gather_ms') else None),
+                               'tune': 'rank 0 measured, every rank imported its choices (film_export_tune / film_import_tune)'}
         if world == 1 and not args.no_split and T == 1:
             # Extra, NOT the headline value: the opt-in precision mode "bf16x6" (exact 3-way bf16 split of every fp32
             # operand, six partial products, fp32 accumulate) on the same workload, with its distance from the

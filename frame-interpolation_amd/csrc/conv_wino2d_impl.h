@@ -104,17 +104,24 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * PXW;
   const int n0 = by * BN;
 
+  auto uniform_ptr = [](const float* q) -> const float* {
+    const unsigned long long v = (unsigned long long)(uintptr_t)q;
+    return reinterpret_cast<const float*>((uintptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                                                        (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v)));
+  };
   // ---- DMA side: request n of this wave fills slots 64 * (wv + NW n) ... + 63 of a stage; lane -> (halo row, pixel, piece) -----
   unsigned rvoff[IPW];
   int rsg = 0, rc0 = 0, rsegC = 0;
-  conv_rsrc_t rrsrc = conv_make_rsrc(p.seg[0].ptr);
+  conv_rsrc_t rrsrc = conv_make_rsrc(uniform_ptr(p.seg[0].ptr));
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
   auto raw_setup_seg = [&]() {   // (once per input segment: the lane's slots are re-derived here rather than kept in registers)
     const ConvSeg& s = p.seg[rsg];
-    rsegC = s.C;
+    rsegC = __builtin_amdgcn_readfirstlane(s.C);
     int be = img + s.boff;
     if (s.bmod && be >= s.bmod) be -= s.bmod;
-    rrsrc = conv_make_rsrc(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride);
+    // (the finished pointer through readfirstlane: should hipcc ever reload `p` with vector loads - it does behind an atomic - a buffer
+    // resource in VGPRs cannot feed the DMA statement - nor a buffer load without a waterfall loop)
+    rrsrc = conv_make_rsrc(uniform_ptr(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride));
     int ln = lane;
     asm volatile("" : "+v"(ln));   // opaque: keeps the slot arithmetic below out of the K loop's live registers
 #pragma unroll
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 
   // ---- weights: [Cout / 32][chunk][mu][nu][K half][32][4] floats; this wave reads slab (ct, kc, mu): 6 x 1 KB -----------------
   const int nkc = p.Ctot / 8, nsc = nkc / 2;
-  const conv_rsrc_t brsrc = conv_make_rsrc(p.w);
+  const conv_rsrc_t brsrc = conv_make_rsrc(uniform_ptr(p.w));
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const int ct = n0 / 32 + ng;
   auto slab = [&](int kc) { return (unsigned)(((ct * nkc + (kc < nkc ? kc : nkc - 1)) * 4 + mu) * 6) * 1024u; };

@@ -411,7 +411,12 @@ int copy_out_string(film_t* h, const std::string& s, char* buf, int64_t cap, int
 // =============================================================================================
 extern "C" {
 
-const char* film_version(void) { return "gfx950;film_hip r3"; }
+int film_to_uint8(const float* src, unsigned char* dst, int64_t n, void* stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return FILM_ERR_INVALID;
+  return film_launch_to_uint8(src, dst, n, (hipStream_t)stream) == hipSuccess ? FILM_OK : FILM_ERR_HIP;
+}
+
+const char* film_version(void) { return "gfx950;film_hip r4"; }
 
 int film_default_config(film_config* cfg) {
   if (!cfg) return FILM_ERR_INVALID;

@@ -261,5 +261,7 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s);
 hipError_t film_launch_pack_flow(const PackFlowParams& p, hipStream_t s);
 hipError_t film_launch_frame_to_tiles(const TileMapParams& p, hipStream_t s);   // pad + image_to_patches
 hipError_t film_launch_tiles_to_frame(const TileMapParams& p, hipStream_t s);   // crop + patches_to_image
+// write_image's rounding on the device: dst[i] = uint8(clip(src[i] * 255, 0, 255) + 0.5)  (eval/util.py:51-52)
+hipError_t film_launch_to_uint8(const float* src, uint8_t* dst, int64_t n, hipStream_t s);
 // fills n floats with a deterministic pseudo-random pattern in [-1, 1) (autotune inputs only)
 hipError_t film_launch_fill_random(float* dst, int64_t n, uint32_t seed, hipStream_t s);

@@ -402,6 +402,25 @@ __global__ __launch_bounds__(256) void fill_random_kernel(float* dst, int64_t n,
   }
 }
 
+// eval/util.py:51-52 (write_image): clip(x * 255, 0, 255) + 0.5, truncated to uint8 - the same float32 operations in the same order
+// (no fused multiply-add: the file is built with -ffp-contract=off), four values per thread
+__global__ __launch_bounds__(256) void to_uint8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, int64_t n) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= n) return;
+  auto cv = [](float x) -> uint32_t {
+    float v = x * 255.f;
+    v = v < 0.f ? 0.f : v;      // np.clip = minimum(maximum(x, 0), 255)
+    v = v > 255.f ? 255.f : v;
+    return (uint32_t)(v + 0.5f);
+  };
+  if (i + 3 < n && ((reinterpret_cast<uintptr_t>(src + i) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst + i) & 3) == 0)) {
+    const float4 v = *reinterpret_cast<const float4*>(src + i);
+    *reinterpret_cast<uint32_t*>(dst + i) = cv(v.x) | (cv(v.y) << 8) | (cv(v.z) << 16) | (cv(v.w) << 24);
+  } else {
+    for (int64_t k = i; k < n && k < i + 4; ++k) dst[k] = (uint8_t)cv(src[k]);
+  }
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 
 }  // namespace
@@ -514,6 +533,12 @@ hipError_t film_launch_frame_to_tiles(const TileMapParams& p, hipStream_t s) {
 
 hipError_t film_launch_tiles_to_frame(const TileMapParams& p, hipStream_t s) {
   hipLaunchKernelGGL(tiles_to_frame_kernel, dim3(blocks_for((int64_t)p.ntiles * p.ph * p.pw * 3)), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+hipError_t film_launch_to_uint8(const float* src, uint8_t* dst, int64_t n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(to_uint8_kernel, dim3(blocks_for((n + 3) / 4)), dim3(256), 0, s, src, dst, n);
   return hipGetLastError();
 }
 

@@ -93,10 +93,31 @@ def write_video(path: str, frames: List[np.ndarray], fps: int) -> None:
         p.wait()
 
 
+def write_video_uint8(path: str, frames: List[np.ndarray], fps: int) -> None:
+    ffmpeg = util.get_ffmpeg_path()
+    h, w = frames[0].shape[:2]
+    cmd = [ffmpeg, '-y', '-f', 'rawvideo', '-pix_fmt', 'rgb24', '-s', f'{w}x{h}', '-r', str(fps), '-i', '-',
+           '-pix_fmt', 'yuv420p', path]
+    with subprocess.Popen(cmd, stdin=subprocess.PIPE) as p:
+        for f in frames:
+            p.stdin.write(f.tobytes())
+        p.stdin.close()
+        p.wait()
+
+
 def process_directory(directory: str, it, args) -> int:
     inputs = list_input_frames(directory)
     if len(inputs) < 2:
         return 0
+    frames_dir = f'{directory}/interpolated_frames'
+    output_frames([], frames_dir)      # (creates the directory / removes stale frame_*.png, as the reference does before writing)
+    fast = util.interpolate_pairs_to_files(inputs, 0, len(inputs) - 1, len(inputs) - 1, args.times_to_interpolate, it, frames_dir,
+                                           keep=bool(args.output_video))
+    if fast is not None:               # the device pipeline (HIP-backed Interpolator): same files, encoded while the GPU works
+        n, kept = fast
+        if args.output_video:
+            write_video_uint8(f'{directory}/interpolated.mp4', kept, args.fps)
+        return n
     frames = list(util.interpolate_recursively_from_files(inputs, args.times_to_interpolate, it))
     output_frames(frames, f'{directory}/interpolated_frames')
     if args.output_video:
@@ -170,6 +191,9 @@ def process_pair_range(directory: str, first: int, end: int, n_pairs: int, it, a
     else:
         os.makedirs(frames_dir, exist_ok=True)
     step = 2 ** args.times_to_interpolate
+    fast = util.interpolate_pairs_to_files(inputs, first, end, n_pairs, args.times_to_interpolate, it, frames_dir)
+    if fast is not None:
+        return fast[0]
     n = 0
     for p in range(first, end):
         seq = list(util.interpolate_recursively_from_files(inputs[p:p + 2], args.times_to_interpolate, it))

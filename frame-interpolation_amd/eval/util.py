@@ -52,6 +52,74 @@ def write_image(filename: str, image: np.ndarray) -> None:
         Image.fromarray(pixels, 'RGB').save(filename, format='PNG')
 
 
+def write_image_uint8(filename: str, pixels: np.ndarray) -> None:
+    """write_image for pixels that are already quantised (uint8 [H,W,3]): the same encoder settings, so the same file bytes as
+    write_image(filename, x) whenever pixels == to_uint8(x)."""
+    Image = _pil()
+    if os.path.splitext(filename)[1] == '.jpg':
+        Image.fromarray(pixels, 'RGB').save(filename, format='JPEG', quality=95)
+    else:
+        Image.fromarray(pixels, 'RGB').save(filename, format='PNG')
+
+
+def interpolate_pairs_to_files(inputs: List[str], first: int, end: int, n_pairs: int, times_to_interpolate: int,
+                               interpolator: 'interpolator_lib.Interpolator', frames_dir: str, keep: bool = False,
+                               workers: Optional[int] = None):
+    """Input pairs [first, end) of `inputs` -> frames_dir/frame_%03d.png with the reference's numbering (frame k of pair p at
+    p * 2^T + k; the owner of the last pair also writes the final input frame - eval/interpolator_cli.py:127-149,
+    eval/util.py:94-123), as a PIPELINE (round 4): the recursion of a pair runs breadth first on the device
+    (film_hip.recursive.Uint8FrameStream), each depth's frames are quantised on the device, cross PCIe as bytes on a copy stream
+    and are PNG-encoded by a thread pool while the next depth / the next pair computes; the next input file is decoded meanwhile.
+    Byte-identical files to write_image(interpolate_recursively_from_files(...)).  Returns (frames written, [uint8 frames in
+    order] if keep else None).  Needs the HIP-backed Interpolator; returns None for any other callable (callers fall back)."""
+    engine = getattr(interpolator, 'engine', None)
+    if engine is None or engine.device < 0 or os.environ.get('FILM_HOST_RECURSION') == '1':
+        return None
+    import concurrent.futures
+    import torch
+    from film_hip.recursive import Uint8FrameStream
+    from film_hip.torch_io import DeviceInterpolator
+    T = times_to_interpolate
+    step = 2 ** T
+    dev = torch.device('cuda', engine.device)
+    dev_it = DeviceInterpolator(engine, align=interpolator.align, block_shape=interpolator.block_shape)
+    nw = workers or max(2, min(32, (os.cpu_count() or 4)))
+    kept = {} if keep else None
+    written = 0
+    with torch.cuda.device(dev), concurrent.futures.ThreadPoolExecutor(max_workers=nw) as enc:
+        stream = Uint8FrameStream(dev_it, engine)
+        pending = []
+
+        def emit(index: int, pixels: np.ndarray) -> None:
+            if kept is not None:
+                kept[index] = pixels
+            pending.append(enc.submit(write_image_uint8, f'{frames_dir}/frame_{index:03d}.png', pixels))
+
+        nxt = enc.submit(read_image, inputs[first]) if end > first else None
+        for p in range(first, end):
+            f1 = nxt.result()
+            nxt = enc.submit(read_image, inputs[p + 1])
+            f2 = nxt.result() if T == 0 else None
+            emit(p * step, to_uint8(f1))
+            written += 1
+            if T > 0:
+                a = torch.from_numpy(np.ascontiguousarray(f1, dtype=np.float32)).to(dev, non_blocking=False)
+                f2 = nxt.result()
+                b = torch.from_numpy(np.ascontiguousarray(f2, dtype=np.float32)).to(dev, non_blocking=False)
+                futs = stream.run(a, b, T, lambda k, px, base=p * step: emit(base + k, px))
+                for fu in futs:
+                    fu.result()
+                written += step - 1
+            if p == n_pairs - 1:
+                emit((p + 1) * step, to_uint8(f2))
+                written += 1
+        for fu in pending:
+            fu.result()
+        stream.close()
+    engine.save_tune_cache()
+    return written, ([kept[i] for i in sorted(kept)] if kept is not None else None)
+
+
 def _recursive_generator(
         frame1: np.ndarray, frame2: np.ndarray, num_recursions: int,
         interpolator: 'interpolator_lib.Interpolator',

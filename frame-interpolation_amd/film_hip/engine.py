@@ -45,7 +45,7 @@ EXPORTED_SYMBOLS = (
     'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_export_layouts', 'film_forward',
     'film_interpolate',
     'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version',
-    'film_export_tune', 'film_import_tune')
+    'film_export_tune', 'film_import_tune', 'film_to_uint8')
 
 _lib = None
 
@@ -95,6 +95,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_version.restype = cp
     lib.film_export_tune.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, i64p]
     lib.film_import_tune.argtypes = [vp, cp]
+    lib.film_to_uint8.argtypes = [vp, vp, ctypes.c_int64, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ('film_destroy',):
@@ -278,6 +279,12 @@ class FilmEngine:
         self._check(self._lib.film_interpolate(self._h, ctypes.c_void_p(x0_ptr), ctypes.c_void_p(x1_ptr), b, h, w,
                                                int(align or 0), bh, bw, ctypes.c_void_p(out_ptr), FILM_MEM_DEVICE,
                                                ctypes.c_void_p(stream) if stream else None))
+
+    def to_uint8_device(self, src_ptr: int, dst_ptr: int, n: int, stream: Optional[int] = None) -> None:
+        """film_to_uint8: write_image's quantisation (eval/util.py:51-52) of n device floats into n device bytes, asynchronous."""
+        rc = self._lib.film_to_uint8(ctypes.c_void_p(src_ptr), ctypes.c_void_p(dst_ptr), int(n), ctypes.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise FilmError(rc, 'film_to_uint8 failed')
 
     def set_option(self, key: str, value: int) -> None:
         self._check(self._lib.film_set_option(self._h, key.encode(), int(value)))

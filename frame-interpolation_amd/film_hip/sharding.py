@@ -57,6 +57,15 @@ def broadcast_weights(engine, dist, src: int = 0, device=None) -> None:
             engine.import_packed(blob.numpy())
 
 
+def share_tune(engine, dist, src: int = 0) -> None:
+    """Every rank adopts rank `src`'s autotune choices (film_export_tune text: per conv shape the fastest tile of its kernel
+    family - they cannot change a result, only the speed): one measurement for the job instead of one per rank."""
+    objs = [engine.export_tune() if dist.get_rank() == src else None]
+    dist.broadcast_object_list(objs, src=src)
+    if dist.get_rank() != src and objs[0]:
+        engine.import_tune(objs[0])
+
+
 def sharded_interpolator(model_path, align, block_shape, dist, local_rank: int, precision: int = 0, options=None):
     """eval.interpolator.Interpolator of this rank's GPU: rank 0 reads + packs the weights of `model_path`, every
     other rank receives the packed blob by broadcast (RCCL over xGMI) instead of reading and repacking."""
@@ -148,6 +157,8 @@ class TileShardedRecursion:
         self.ntiles = self.block_shape[0] * self.block_shape[1]
         self.tiles = tiles_of_rank(self.block_shape, self.world, self.rank)
         self.counts = [len(tiles_of_rank(self.block_shape, self.world, r)) for r in range(self.world)]
+        self._recv, self._recv_key = None, None
+        self.gather_ms, self.runs = 0.0, 0     # time spent in the gather collective / number of run() calls (bench.py reports it)
 
     def local(self, frame1, frame2, times_to_interpolate: int):
         """This rank's share: [2^T + 1, n_own, ph, pw, 3]."""
@@ -155,11 +166,20 @@ class TileShardedRecursion:
                              extract_tiles(frame2, self.block_shape, self.tiles), times_to_interpolate, self.batch_fn)
 
     def gather(self, local_mids):
-        """[F, n_own, ph, pw, 3] of every rank -> [F, ntiles, ph, pw, 3] on rank dst (None elsewhere).  One gather of
-        equally sized (padded to the largest share) buffers; rank r's tiles are the contiguous range shard_range gives."""
+        """[F, n_own, ph, pw, 3] of every rank -> the list of per-rank receive buffers [F, nmax, ph, pw, 3] on rank dst (None
+        elsewhere; one rank: [local_mids]).  One gather of equally sized (padded to the largest share) buffers; rank r's tiles are
+        the contiguous range shard_range gives.  Before the gather every rank contributes an "ok" flag to an all-reduce: a rank
+        whose recursion failed makes ALL ranks raise instead of leaving the others in the collective until its timeout.  The
+        receive buffers are allocated once per shape and reused (round-3 ADVICE); gather_ms / runs time the collective."""
+        import time
         import torch
         if self.dist is None:
-            return local_mids
+            return [local_mids]
+        failed = local_mids is None
+        flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=self._device(local_mids))
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise RuntimeError(f'rank {self.rank}: a rank failed before the gather' + (' (this one)' if failed else ''))
         nmax = max(self.counts)
         f = local_mids.shape[0]
         send = local_mids
@@ -167,17 +187,58 @@ class TileShardedRecursion:
             send = torch.zeros((f, nmax) + tuple(local_mids.shape[2:]), dtype=local_mids.dtype, device=local_mids.device)
             send[:, :local_mids.shape[1]] = local_mids
         send = send.contiguous()
-        recv = [torch.empty_like(send) for _ in range(self.world)] if self.rank == self.dst else None
+        recv = None
+        if self.rank == self.dst:
+            key = (tuple(send.shape), send.dtype, send.device)
+            if self._recv_key != key:
+                self._recv = [torch.empty_like(send) for _ in range(self.world)]
+                self._recv_key = key
+            recv = self._recv
+        if send.is_cuda:
+            torch.cuda.synchronize(send.device)
+        t0 = time.perf_counter()
         self.dist.gather(send, recv, dst=self.dst)
-        if self.rank != self.dst:
-            return None
-        return torch.cat([recv[r][:, :self.counts[r]] for r in range(self.world) if self.counts[r]], dim=1)
+        if send.is_cuda:
+            torch.cuda.synchronize(send.device)
+        self.gather_ms += (time.perf_counter() - t0) * 1e3
+        self.runs += 1
+        return recv if self.rank == self.dst else None
+
+    def _device(self, t):
+        import torch
+        if t is not None:
+            return t.device
+        return torch.device('cuda', torch.cuda.current_device()) if self.dist.get_backend() == 'nccl' else torch.device('cpu')
 
     def run(self, frame1, frame2, times_to_interpolate: int):
+        """(rank dst) [2^T + 1, H, W, 3]: frame1, the generated frames stitched straight from the receive buffers into ONE output
+        tensor, frame2 - no concatenated copies of the whole sequence in between (4K, T = 6: 1.6 GB each)."""
         import torch
-        seq = self.local(frame1, frame2, times_to_interpolate)
-        mids = self.gather(seq[1:-1].contiguous())
-        if mids is None:
+        err = None
+        try:
+            seq = self.local(frame1, frame2, times_to_interpolate)
+            mine = seq[1:-1].contiguous()
+        except Exception as e:   # noqa: BLE001 - the other ranks must not be left waiting in the gather
+            err, mine = e, None
+            if self.dist is None:
+                raise
+        try:
+            recv = self.gather(mine)
+        except RuntimeError:
+            if err is not None:
+                raise err
+            raise
+        if recv is None:
             return None
-        frames = stitch_tiles(mids, self.block_shape)
-        return torch.cat([frame1[None], frames, frame2[None]], dim=0)
+        bh, bw = self.block_shape
+        f = recv[0].shape[0]
+        ph, pw, c = recv[0].shape[2:]
+        out = torch.empty((f + 2, bh * ph, bw * pw, c), dtype=frame1.dtype, device=frame1.device)
+        out[0] = frame1
+        out[-1] = frame2
+        t = 0
+        for r in range(self.world):
+            for k in range(self.counts[r]):
+                out[1:-1, (t // bw) * ph:(t // bw + 1) * ph, (t % bw) * pw:(t % bw + 1) * pw] = recv[r][:, k]
+                t += 1
+        return out

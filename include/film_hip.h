@@ -211,6 +211,12 @@ int film_plan_json(film_t* h, int B, int H, int W, char* buf, int64_t capacity, 
  * models/film_net/interpolator.py:191-199. */
 int film_get_tap(film_t* h, const char* name, float* dst, int64_t capacity_floats, int64_t dims[4]);
 
+/* write_image's quantisation on the device (replaces the host loop of the reference's eval/util.py:44-59 write_image,
+ * lines 51-52): dst[i] = uint8(clip(src[i] * 255, 0, 255) + 0.5), the same float32 operations in the same order = the same bytes.
+ * src (float32) and dst (uint8) are DEVICE pointers to n values; asynchronous on `stream` (NULL: the default stream) of the
+ * current device.  The frames of a recursion then cross PCIe as 1 byte per value instead of 4.  Returns FILM_OK or a negative error. */
+int film_to_uint8(const float* src, unsigned char* dst, int64_t n, void* stream);
+
 /* CRC-32C (Castagnoli) continued from `crc` (0 to start) over n bytes.  Host helper of the TF-free SavedModel
  * variables reader (frame-interpolation_amd/film_hip/tf_bundle.py), which checks the masked crc32c TensorFlow
  * stores per tensor and per index block; part of replacing tf.saved_model.load (eval/interpolator.py:148). */

@@ -217,3 +217,56 @@ def test_bench_strong_scaling_launcher_world2_plan_only():
     r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
     assert r['n_gpus'] == 2 and r['scaling'] == 'strong' and r['config']['tiles_sharded'] == 4
     assert r['config']['stitched_identical_to_one_rank'] is True and r['config']['weights_identical_on_all_ranks'] is True
+
+
+def _failing_worker(rank, world, port, q):
+    import sys
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    from film_hip.sharding import TileShardedRecursion, share_tune
+
+    def batch_fn(a, c):
+        if rank == 1:
+            raise ValueError('rank 1 breaks inside its recursion')
+        return (a + c) * 0.5
+    g = torch.Generator().manual_seed(3)
+    f1, f2 = torch.rand((32, 48, 3), generator=g), torch.rand((32, 48, 3), generator=g)
+    drv = TileShardedRecursion(batch_fn, [2, 2], dist)
+    try:
+        drv.run(f1, f2, 2)
+        what = 'no error'
+    except ValueError as e:
+        what = 'own: ' + str(e)
+    except RuntimeError as e:
+        what = 'peer: ' + str(e)
+    # the job is still usable: a tune-cache broadcast (text) behind the failed run
+    eng = FilmEngine(TINY, device=-1)
+    share_tune(eng, dist, src=0)
+    q.put((rank, what, eng.export_tune().startswith('# film_hip tune cache')))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_aborts_the_tile_gather_on_every_rank():
+    """Round-3 ADVICE: a rank that raises inside its share of the recursion used to leave the others in the gather until the
+    collective timeout.  Now every rank all-reduces an ok flag first: the failing rank re-raises its own error, the others raise
+    too, nobody hangs - and the process group is still usable afterwards (share_tune broadcast)."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1].startswith('peer: ') and 'a rank failed' in res[0][1] and res[0][2]
+    assert res[1][1] == 'own: rank 1 breaks inside its recursion' and res[1][2]

@@ -176,6 +176,51 @@ def test_interpolator_cli_writes_reference_frames(published, tmp_path, monkeypat
         assert np.array_equal(util.to_uint8(wnt), (got * 255 + 0.5).astype(np.uint8)), f
 
 
+def test_device_to_uint8_and_the_file_pipeline_write_the_reference_bytes(published, tmp_path, monkeypatch):
+    """Round 4, SURVEY 8 f1: film_to_uint8 gives write_image's bytes (eval/util.py:51-52) on edge values (negative, > 1, exact
+    k / 255 and k / 255 +- 1 ulp, halves) and on random data, odd lengths and unaligned pointers included; and the device
+    pipeline of the CLI (breadth-first recursion, device quantisation, uint8 D2H on a copy stream, thread-pool PNG encode) writes
+    byte-identical FILES to the round-3 path (float32 frames back, host to_uint8, serial encode) - three input frames, T = 3,
+    tiled."""
+    import filecmp
+    import torch
+    from eval import interpolator_cli as cli
+    from eval import util
+    opt, w, eng = published
+    rng = np.random.default_rng(12)
+    k = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    edge = np.concatenate([np.array([-1.0, -1e-9, 0.0, 1.0, 1.0 + 1e-6, 2.5, 0.5 / 255, 1.5 / 255, 254.5 / 255, 0.49999997 / 255], np.float32),
+                           k, np.nextafter(k, np.float32(2)), np.nextafter(k, np.float32(-1)),
+                           (np.arange(256, dtype=np.float32) + np.float32(0.5)) / np.float32(255.0), rng.random(100003, dtype=np.float32) * 1.2 - 0.1])
+    for off in (0, 1, 3):
+        x = edge[off:]
+        src = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        dst = torch.full((x.size + 5,), 77, dtype=torch.uint8, device='cuda')
+        eng.to_uint8_device(src.data_ptr(), dst.data_ptr() + off, x.size - off, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        assert np.array_equal(got[off:off + x.size - off], util.to_uint8(x[:x.size - off])), off
+        assert (got[:off] == 77).all() and (got[x.size:] == 77).all()
+    d = tmp_path / 'clip'
+    d.mkdir()
+    frames = [TI.frame_pair(1, 128, 192, seed=30 + i, shift=(3, -4), fg_shift=(-2, 3))[0][0] for i in range(3)]
+    for i, fr in enumerate(frames):
+        util.write_image(str(d / f'in_{i}.png'), fr)
+    inputs = cli.list_input_frames(str(d))
+    it = _interp(eng, w, align=64, block_shape=[2, 2])
+    new_dir, old_dir = str(tmp_path / 'new'), str(tmp_path / 'old')
+    cli.output_frames([], new_dir)
+    n, kept = util.interpolate_pairs_to_files(inputs, 0, 2, 2, 3, it, new_dir, keep=True)
+    assert n == 17 and len(kept) == 17
+    cli.output_frames(list(util.interpolate_recursively_from_files(inputs, 3, it)), old_dir)
+    names = sorted(os.listdir(old_dir))
+    assert names == sorted(os.listdir(new_dir)) == [f'frame_{i:03d}.png' for i in range(17)]
+    for nm in names:
+        assert filecmp.cmp(os.path.join(new_dir, nm), os.path.join(old_dir, nm), shallow=False), nm
+    for i, nm in enumerate(names):
+        assert np.array_equal(kept[i], (util.read_image(os.path.join(old_dir, nm)) * 255 + 0.5).astype(np.uint8))
+
+
 def test_eval_cli_on_vimeo_sized_triplets(published, tmp_path):
     """eval.eval_cli end to end on the GPU - a model directory on disk (film_weights.npz) loaded by
     Interpolator(model_path), two Vimeo-90K-sized triplet folders (448x256, im1/im2/im3.png), results.csv with

@@ -185,7 +185,8 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     unsigned long long* d_tm;
     const size_t n_tm = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / 32) * 8;
-    CK(hipMalloc(&d_tm, n_tm * 8));
+    CK(hipMalloc(&d_tm, n_tm * 8 + 16384));
+    CK(hipMemset(d_tm, 0, 16384));
     ConvParams p{};
     p.part = reinterpret_cast<float*>(d_tm);
     p.nseg = sh.C2 ? 2 : 1;
