@@ -824,7 +824,8 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
       // capture on the handle's own stream, replay on whichever stream the caller wants
       HIPCHK(h, hipStreamSynchronize(s));
       // two capture streams: lane 1 (small subtrees, coarse flow levels, the t = 0.5 warps) forks from and joins
-      // the main stream; cross-lane ordering = the events found by Planner::analyze_lanes
+      // the main stream; cross-lane ordering = the events found by Planner::analyze_lanes (each op is waited for at
+      // most once by the other lane - see there for why that matters to the replay)
       const size_t nops = P->ops.size();
       if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
       hipError_t ev_err = hipSuccess;
@@ -842,42 +843,18 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
         le = hipEventRecord(event_of(nops), h->stream);
         if (le == hipSuccess) le = hipStreamWaitEvent(h->stream2, event_of(nops), 0);
       }
-      long prev_in_lane[2] = {-1, -1};
-      // Relay edges.  When lane X waits for the LAST op p of lane Y, the next op q of lane Y additionally waits for an
-      // event recorded on X behind that waiter.  By stream order q already follows p, the captured graph has the edge
-      // p -> q (checked with hipGraphGetEdges, tools/experiments/capture_edges.hip), and still: with the flow upsample
-      // fused into the warps AND v = res + up fused into the heads, the replayed graph ran the level-4 t = 0.5 warps
-      // (q) on the PREVIOUS forward's v4 - deterministically, on every shape (ROCm 7.2; tools/dbg_graph_race.py; the
-      // eager path and every other fuse setting were clean).  With the extra parent the replay is bit-identical to the
-      // eager launches on changing inputs (tests/test_gpu_parity.py::test_graph_replay_on_changing_inputs).
-      hipEvent_t relay[2] = {nullptr, nullptr};
-      std::vector<hipEvent_t> relay_pool;
       for (size_t i = 0; i < nops && le == hipSuccess; ++i) {
         const OpDesc& op = P->ops[i];
         const int lane = (two_lanes && op.lane == 1) ? 1 : 0;
         hipStream_t ls = lane ? h->stream2 : h->stream;
-        bool waited_on_last = false;
-        if (two_lanes) {
+        if (two_lanes)
           for (int d : op.xdeps) {
             le = hipStreamWaitEvent(ls, event_of((size_t)d), 0);
             if (le != hipSuccess) break;
-            if ((long)d == prev_in_lane[1 - lane]) waited_on_last = true;
           }
-          if (le == hipSuccess && relay[lane]) { le = hipStreamWaitEvent(ls, relay[lane], 0); relay[lane] = nullptr; }
-        }
         if (le == hipSuccess) le = launch_op(op, P->arena, h->packed_dev, ls);
         if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
-        if (le == hipSuccess && two_lanes && waited_on_last && !relay[1 - lane]) {
-          hipEvent_t e = nullptr;
-          le = hipEventCreateWithFlags(&e, hipEventDisableTiming);
-          if (le != hipSuccess) break;
-          relay_pool.push_back(e);
-          le = hipEventRecord(e, ls);
-          relay[1 - lane] = e;
-        }
-        prev_in_lane[lane] = (long)i;
       }
-      for (hipEvent_t e : relay_pool) P->lane_ev.push_back(e);   // destroyed with the plan
       if (two_lanes && le == hipSuccess) {
         le = hipEventRecord(event_of(nops + 1), h->stream2);
         if (le == hipSuccess) le = hipStreamWaitEvent(h->stream, event_of(nops + 1), 0);

@@ -560,16 +560,24 @@ struct Planner {
     if (op.pack_out.buf >= 0) wr.push_back(access(op.pack_out));
   }
   // For every op: the LAST op of the other lane it conflicts with (RAW, WAR or WAW on overlapping channels of a
-  // buffer).  Waiting for the last one is enough: a lane executes in program order.
+  // buffer).  Waiting for the last one is enough: a lane executes in program order.  For the same reason a wait is
+  // dropped when the lane has already waited for that op or a later one of the other lane: every op of a lane is then
+  // waited for at most ONCE by the other lane, i.e. a graph node has at most two children (its lane successor and one
+  // cross-lane waiter).  That is not only tidier: the graph replay of HIP 7.0/7.2 starts a node whose ONLY parent
+  // already has >= 5 earlier-captured children without waiting for that parent
+  // (tools/experiments/graph_single_parent_race.hip).
   void analyze_lanes() {
     const size_t n = P->ops.size();
     std::vector<std::vector<Access>> rd(n), wr(n);
     for (size_t i = 0; i < n; ++i) accesses(P->ops[i], rd[i], wr[i]);
+    long waited[2] = {-1, -1};   // per lane: the latest op of the other lane it has waited for
     for (size_t j = 0; j < n; ++j) {
       OpDesc& oj = P->ops[j];
+      const int lj = oj.lane ? 1 : 0;
       for (size_t ii = j; ii-- > 0;) {
         const OpDesc& oi = P->ops[ii];
-        if (oi.lane == oj.lane) continue;
+        if ((oi.lane ? 1 : 0) == lj) continue;
+        if ((long)ii <= waited[lj]) break;   // ordered already (and so is everything before it)
         bool hit = false;
         for (const Access& w : wr[ii]) {
           for (const Access& r : rd[j]) hit |= overlap(w, r);
@@ -577,7 +585,7 @@ struct Planner {
         }
         for (const Access& r : rd[ii])
           for (const Access& w2 : wr[j]) hit |= overlap(r, w2);
-        if (hit) { oj.xdeps.push_back((int)ii); P->ops[ii].signal = true; break; }
+        if (hit) { oj.xdeps.push_back((int)ii); P->ops[ii].signal = true; waited[lj] = (long)ii; break; }
       }
     }
   }

@@ -95,16 +95,17 @@ def interpolate_pairs_to_files(inputs: List[str], first: int, end: int, n_pairs:
                 kept[index] = pixels
             pending.append(enc.submit(write_image_uint8, f'{frames_dir}/frame_{index:03d}.png', pixels))
 
-        nxt = enc.submit(read_image, inputs[first]) if end > first else None
+        # decode ahead: the two inputs of the first pair at once, then always one file beyond the pair being interpolated
+        reads = {i: enc.submit(read_image, inputs[i]) for i in range(first, min(first + 2, end + 1))} if end > first else {}
         for p in range(first, end):
-            f1 = nxt.result()
-            nxt = enc.submit(read_image, inputs[p + 1])
-            f2 = nxt.result() if T == 0 else None
+            f1 = reads.pop(p).result() if p in reads else read_image(inputs[p])
+            f2 = reads[p + 1].result()                      # (stays in `reads`: it is the next pair's first frame)
+            if p + 2 <= end:
+                reads[p + 2] = enc.submit(read_image, inputs[p + 2])
             emit(p * step, to_uint8(f1))
             written += 1
             if T > 0:
                 a = torch.from_numpy(np.ascontiguousarray(f1, dtype=np.float32)).to(dev, non_blocking=False)
-                f2 = nxt.result()
                 b = torch.from_numpy(np.ascontiguousarray(f2, dtype=np.float32)).to(dev, non_blocking=False)
                 futs = stream.run(a, b, T, lambda k, px, base=p * step: emit(base + k, px))
                 for fu in futs:

@@ -446,11 +446,14 @@ def test_autotuned_tiles_do_not_change_results(published):
     assert np.array_equal(tuned, ref)
 
 
-@pytest.mark.parametrize('fuse', [31, 15, 0])
+@pytest.mark.parametrize('fuse', [31, 15, 3, 0])
 def test_graph_replay_on_changing_inputs(published, fuse):
     """The two-lane hipGraph replay vs eager launches with inputs that CHANGE every forward (a missing edge or a stale
     read in the replayed graph shows up as the previous forward's data; equal inputs would hide it): image and every
-    aligned-pyramid level bit-identical, several shapes, default fusion options and none."""
+    aligned-pyramid level bit-identical, several shapes, default fusion options and none.  (1, 576, 960) with fuse = 3 is
+    the plan whose level-4 t = 0.5 warp had the flow head as its ONLY parent while five flow-level-3..1 ops waited for the
+    same head: HIP 7.x replays such a node early (tools/experiments/graph_single_parent_race.hip); the planner now emits
+    every cross-lane wait once.)"""
     from film_hip.engine import FilmEngine
     opt, w, _ = published
     eg = FilmEngine(opt, device=0)
@@ -460,7 +463,7 @@ def test_graph_replay_on_changing_inputs(published, fuse):
     ee.set_weights(w)
     ee.set_option('fuse', fuse)
     ee.set_option('graph', 0)
-    for (b, h, wd) in ((1, 64, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320)):
+    for (b, h, wd) in ((1, 64, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320), (1, 576, 960)):
         for it in range(3):
             rng = np.random.default_rng(1000 * h + it)
             x0 = rng.random((b, h, wd, 3), dtype=np.float32)

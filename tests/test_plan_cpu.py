@@ -342,6 +342,14 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
                     any(hit(r, w2) for r in ri for w2 in wj)
                 if conflict:
                     assert i in before[j], (ops[i]['tag'], ops[j]['tag'])
+        # no implied waits: an op is waited for at most once by the other lane, so a captured graph node has at most two
+        # children (HIP 7.x replays a node whose only parent has >= 5 earlier children without waiting for that parent:
+        # tools/experiments/graph_single_parent_race.hip)
+        waiters = [d for o in ops for d in o['xdeps']]
+        assert len(waiters) == len(set(waiters))
+        for lane in (0, 1):
+            seq = [d for o in ops if o['lane'] == lane for d in o['xdeps']]
+            assert seq == sorted(seq)
 
 
 def test_plan_interpreter_fused_ops_published_256(published_packed):

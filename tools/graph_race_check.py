@@ -9,7 +9,9 @@ w = W.make_synthetic_weights(PUBLISHED, seed=0)
 fuse = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 eg = FilmEngine(PUBLISHED, device=0); eg.set_weights(w); eg.set_option('fuse', fuse)
 ee = FilmEngine(PUBLISHED, device=0); ee.set_weights(w); ee.set_option('fuse', fuse); ee.set_option('graph', 0)
-for (b, h, wd) in ((1, 64, 64), (1, 128, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320), (1, 576, 960)):
+import os
+SHAPES = ((1, 64, 64), (1, 128, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320), (1, 576, 960))[:int(os.environ.get('RACE_SHAPES', '6'))]
+for (b, h, wd) in SHAPES:
     worst = 0.0
     for it in range(4):
         rng = np.random.default_rng(100 * h + it)
