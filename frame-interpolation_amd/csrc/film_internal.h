@@ -86,8 +86,10 @@ struct OpDesc {
   int halo = 0;                       // conv: runs on conv_halo_kernel (decided by shape, see Planner::conv)
   // generic views
   View in, in2, out;
-  View pack_b, pack_f, pack_out;   // warp: fused pack_flow (0.5 * flows into the aligned pyramid)
-  View img_in, img_out;   // warp: fused 3-channel image warp with the same flow (t = 0.5 stage)
+  // warp: the fused sixteen miscellaneous channels of an aligned level (t = 0.5 stage): img_in = both images [2 NB][H][W][3],
+  // pack_b / pack_f = backward / forward flow, img_out = [warp(img0) 3 | warp(img1) 3 | 0.5 bflow 2 | 0.5 fflow 2 | 0 x 6]
+  View pack_b, pack_f;
+  View img_in, img_out;
   View pw_out; int pw_cout = 0;   // conv: fused 1x1 convolution behind it (weights w2_off / b2_off) writes pw_out; `out` is not written then
   View in3, out2;   // warp: coarser flow to upsample / the upsampled flow it stores; flow heads: in2 = upsampled flow, out2 = v = out + in2
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims

@@ -148,18 +148,19 @@ struct WarpParams {
   // and it is written to flow_out [NB][H][W][2] (C % 4 == 0 launches only) - the former flow_up launch.
   const float* coarse;
   float* flow_out;
-  // Fused 3-channel image warp of the t = 0.5 stage (interpolator.py:167-178 warps [image | features] as one tensor): the
-  // same flow also samples src3 [NB][H][W][3] (pixel stride s3stride) into dst3 (pixel stride d3stride); W extra units
-  // per row behind the feature units of a row band do it - the former warp_c3 launch.  nullptr: none.
+  // Fused sixteen miscellaneous channels of an aligned-pyramid level (interpolator.py:167-183 warps [image | features] as one
+  // tensor and appends the two half flows): dst3[pix] = {warp(src3, 0.5 pack_b) 3, warp(src3b, 0.5 pack_f) 3, 0.5 pack_b 2,
+  // 0.5 pack_f 2, 0 x 6}, pixel stride d3stride, produced by one more 16-lane channel slice of every pixel tile - the former
+  // warp_c3 x 2 + pack_flow launches.  src3 / src3b: the two images [NB][H][W][3] (pixel stride s3stride), pack_b / pack_f:
+  // backward / forward flow [NB][H][W][2].  dst3 == nullptr: none.
   const float* src3;
+  const float* src3b;
   int s3stride;
   float* dst3;
   int d3stride;
-  // Fused pack_flow (PackFlowParams) for the same pixels: pack_dst[pix] = {0.5 bflow, 0.5 fflow, 0 x 6}; nullptr: none.
   const float* pack_b;
   const float* pack_f;
-  float* pack_dst;
-  int pack_stride;
+  int variant = -1;   // experiment knob (tools/warp_bench.hip): kernel MODE, -1 = the default
 };
 
 // Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:

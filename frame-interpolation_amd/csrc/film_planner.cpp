@@ -451,30 +451,28 @@ struct Planner {
         View fl = view(v[l], (1 - s) * B, 0, 2);
         warp(tg + ":warp_feat" + std::to_string(s), view(feat[l], s * B, 0, fc[l]), fl,
              view(aligned[l], 0, s * fc[l], fc[l]), B, HL(l), WL(l), 0.5f);
-        if (h->opt_fuse & 4) {   // the 3-channel image rides in the same launch (extra row units)
-          OpDesc& w = P->ops.back();
-          w.tag += "+img";
-          w.img_in = view(img[l], s * B, 0, 3);
-          w.img_out = view(aligned[l], 0, 2 * fc[l] + 3 * s, 3);
-          w.bytes += 4.0 * B * HL(l) * WL(l) * 6.0;
-        } else
-        warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
-             view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f, false);
+        if (!(h->opt_fuse & 4))
+          warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
+               view(aligned[l], 0, 2 * fc[l] + 3 * s, 3), B, HL(l), WL(l), 0.5f, false);
       }
-      if (h->opt_fuse & 4) {   // 0.5 * flows ride in the second feature warp of the level
+      if (h->opt_fuse & 4) {
+        // the sixteen miscellaneous channels [warp(img0) 3 | warp(img1) 3 | 0.5 bflow 2 | 0.5 fflow 2 | 0 x 6] ride in the second
+        // feature warp of the level as one more channel slice (one full 64-byte line per pixel and store)
         OpDesc& w = P->ops.back();
-        w.tag += "+flows";
-        w.pack_b = view(v[l], B, 0, 2);   // backward flow (d = 1)
-        w.pack_f = view(v[l], 0, 0, 2);   // forward flow  (d = 0)
-        w.pack_out = view(aligned[l], 0, 2 * fc[l] + 6, 10);
+        w.tag += "+misc16";
+        w.img_in = view(img[l], 0, 0, 3);             // [2B]: image 0, image 1
+        w.img_out = view(aligned[l], 0, 2 * fc[l], 16);
+        w.pack_b = view(v[l], B, 0, 2);   // backward flow (d = 1): samples image 0
+        w.pack_f = view(v[l], 0, 0, 2);   // forward flow  (d = 0): samples image 1
+        w.bytes += 4.0 * B * HL(l) * WL(l) * 12.0;   // both 3-channel images, read + written (SURVEY 8d counts the image with the features)
       } else {
-      OpDesc pk;
-      pk.kind = OP_PACK_FLOW; pk.tag = tg + ":flows";
-      pk.in = view(v[l], B, 0, 2);   // backward flow (d = 1)
-      pk.in2 = view(v[l], 0, 0, 2);  // forward flow  (d = 0)
-      pk.out = view(aligned[l], 0, 2 * fc[l] + 6, 10);
-      pk.n = (int64_t)B * HL(l) * WL(l); pk.bytes = 4.0 * pk.n * 14;
-      P->ops.push_back(pk);
+        OpDesc pk;
+        pk.kind = OP_PACK_FLOW; pk.tag = tg + ":flows";
+        pk.in = view(v[l], B, 0, 2);   // backward flow (d = 1)
+        pk.in2 = view(v[l], 0, 0, 2);  // forward flow  (d = 0)
+        pk.out = view(aligned[l], 0, 2 * fc[l] + 6, 10);
+        pk.n = (int64_t)B * HL(l) * WL(l); pk.bytes = 4.0 * pk.n * 14;
+        P->ops.push_back(pk);
       }
       for (size_t q = first_align_op; q < P->ops.size(); ++q) P->ops[q].lane = 1;
     };
@@ -557,7 +555,6 @@ struct Planner {
     if (op.pw_out.buf >= 0) wr.push_back(access(op.pw_out));
     if (op.out2.buf >= 0) wr.push_back(access(op.out2));
     if (op.img_out.buf >= 0) wr.push_back(access(op.img_out));
-    if (op.pack_out.buf >= 0) wr.push_back(access(op.pack_out));
   }
   // For every op: the LAST op of the other lane it conflicts with (RAW, WAR or WAW on overlapping channels of a
   // buffer).  Waiting for the last one is enough: a lane executes in program order.  For the same reason a wait is
@@ -659,7 +656,6 @@ std::string plan_json(film_t* h, const Plan& P) {
     json_view(o, "img_out", op.img_out, P); o << ",";
     json_view(o, "pack_b", op.pack_b, P); o << ",";
     json_view(o, "pack_f", op.pack_f, P); o << ",";
-    json_view(o, "pack_out", op.pack_out, P); o << ",";
     json_view(o, "out", op.out, P);
     o << ",\"segs\":[";
     for (int k = 0; k < op.nseg; ++k) {

@@ -209,14 +209,17 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             else:
                 flow = np.ascontiguousarray(_view(arena, op['in2'], nb, h, w))
             _view(arena, op['out'], nb, h, w)[...] = fo.warp(src, np.float32(op['fscale']) * flow)
-            if op.get('img_in', {}).get('buf'):     # fused 3-channel image warp with the same flow
-                im = np.ascontiguousarray(_view(arena, op['img_in'], nb, h, w))
-                _view(arena, op['img_out'], nb, h, w)[...] = fo.warp(im, np.float32(op['fscale']) * flow)
-            if op.get('pack_out', {}).get('buf'):   # fused pack_flow
-                out = _view(arena, op['pack_out'], nb, h, w)
-                out[..., 0:2] = _view(arena, op['pack_b'], nb, h, w) * np.float32(0.5)
-                out[..., 2:4] = _view(arena, op['pack_f'], nb, h, w) * np.float32(0.5)
-                out[..., 4:10] = 0
+            if op.get('img_out', {}).get('buf'):    # fused sixteen miscellaneous channels of the aligned level
+                ims = np.ascontiguousarray(_view(arena, op['img_in'], 2 * nb, h, w))
+                bf = np.ascontiguousarray(_view(arena, op['pack_b'], nb, h, w))
+                ff = np.ascontiguousarray(_view(arena, op['pack_f'], nb, h, w))
+                out = _view(arena, op['img_out'], nb, h, w)
+                assert op['img_out']['C'] == 16 and op['fscale'] == 0.5
+                out[..., 0:3] = fo.warp(ims[:nb], np.float32(0.5) * bf)    # image 0 <- backward flow
+                out[..., 3:6] = fo.warp(ims[nb:], np.float32(0.5) * ff)    # image 1 <- forward flow
+                out[..., 6:8] = bf * np.float32(0.5)
+                out[..., 8:10] = ff * np.float32(0.5)
+                out[..., 10:16] = 0
         elif k == 'pack_flow':
             m = op['n']
             bf = _view(arena, op['in'], 1, 1, m)

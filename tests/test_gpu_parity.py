@@ -476,6 +476,65 @@ def test_graph_replay_on_changing_inputs(published, fuse):
     ee.close()
 
 
+def _warp_numpy(src, flow, fscale):
+    """warp_vec_kernel's arithmetic in numpy float32 (no FMA anywhere): q = coord + s * flow, floor clamped to
+    [0, size - 2], alpha clamped to [0, 1], top = ax * (tr - tl) + tl, bot likewise, out = ay * (bot - top) + top."""
+    B, H, W, _ = src.shape
+    f32 = np.float32
+    yy, xx = np.meshgrid(np.arange(H, dtype=f32), np.arange(W, dtype=f32), indexing='ij')
+    qy = yy[None] + f32(fscale) * flow[..., 1]
+    qx = xx[None] + f32(fscale) * flow[..., 0]
+    fy = np.minimum(np.maximum(np.floor(qy), f32(0)), f32(H - 2))
+    fx = np.minimum(np.maximum(np.floor(qx), f32(0)), f32(W - 2))
+    ay = np.minimum(np.maximum(qy - fy, f32(0)), f32(1))[..., None]
+    ax = np.minimum(np.maximum(qx - fx, f32(0)), f32(1))[..., None]
+    iy, ix = fy.astype(np.int64), fx.astype(np.int64)
+    bi = np.arange(B)[:, None, None]
+    tl, tr = src[bi, iy, ix], src[bi, iy, ix + 1]
+    bl, br = src[bi, iy + 1, ix], src[bi, iy + 1, ix + 1]
+    top = ax * (tr - tl) + tl
+    bot = ax * (br - bl) + bl
+    return ay * (bot - top) + top
+
+
+@pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 192, 320), (1, 320, 448), (1, 576, 960)])
+def test_warp_corner_sharing_is_bit_exact(published, b, h, w):
+    """warp_vec_kernel takes a corner from the row above / the lane of pixel x + 1 when the source pixel indices say it
+    is the same pixel, and loads it otherwise: every t = 0.5 feature and image warp of a forward (flows of the network
+    itself: mostly shared corners, some not; rows that end inside a 16-pixel workgroup; levels down to 4x4) must have
+    exactly the bits of the gather computed in numpy from the engine's own feature / image / flow taps."""
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    opt, wts, _ = published
+    eng = FilmEngine(opt, device=0)
+    eng.set_weights(wts)
+    rng = np.random.default_rng(h * w)
+    x0 = rng.random((b, h, w, 3), dtype=np.float32)
+    x1 = np.roll(x0, (2, -3), axis=(1, 2)) + rng.normal(0, 0.02, x0.shape).astype(np.float32)
+    eng.forward(x0, x1)
+    fc = W.feature_channels(opt)
+    shared = []
+    for l in range(opt.fusion_pyramid_levels):
+        feat, img, a = eng.tap(f'feat{l}'), eng.tap(f'img{l}'), eng.tap(f'aligned{l}')
+        v = eng.tap(f'v{l}' if l < opt.pyramid_levels - 1 else f'res{l}')
+        C = fc[l]
+        for s in range(2):
+            fl = v[(1 - s) * b:(2 - s) * b]       # image s is sampled with the flow of the opposite direction
+            want = _warp_numpy(feat[s * b:(s + 1) * b][..., :C], fl, 0.5)
+            assert np.array_equal(a[..., s * C:(s + 1) * C], want), (l, s)
+            want3 = _warp_numpy(img[s * b:(s + 1) * b], fl, 0.5)
+            assert np.array_equal(a[..., 2 * C + 3 * s:2 * C + 3 * s + 3], want3), (l, s, 'image')
+            # 0.5 * flow rides in the same sixteen-channel slice: backward flow (image 0's) first
+            assert np.array_equal(a[..., 2 * C + 6 + 2 * s:2 * C + 8 + 2 * s], fl * np.float32(0.5)), (l, s, 'flow')
+            H, Wd = fl.shape[1:3]
+            if Wd > 2:
+                fx = np.clip(np.floor(np.arange(Wd, dtype=np.float32) + np.float32(0.5) * fl[..., 0]), 0, Wd - 2)
+                shared.append(float((fx[:, :, 1:] == fx[:, :, :-1] + 1).mean()))
+        assert not a[..., 2 * C + 10:].any(), l
+    assert 0.3 < min(shared) and max(shared) <= 1.0, shared    # both paths are exercised
+    eng.close()
+
+
 def test_fused_rgb_head_is_bit_identical(published):
     """Option fuse bit 16 (the RGB head's 1x1 convolution inside the epilogue of the last decoder layer, whose 64-channel
     output is then never written) sums in conv_pw_kernel's order: the image has the same bits with and without it."""

@@ -313,7 +313,7 @@ def test_lane_analysis_orders_every_conflict(tiny_weights):
             rd = [acc(sg['v']) for sg in op.get('segs', [])] if op['kind'] == 'conv_mfma' else [acc(op.get('in')), acc(op.get('in2'))]
             rd = list(rd)
             rd += [acc(op.get('in3')), acc(op.get('img_in')), acc(op.get('pack_b')), acc(op.get('pack_f'))]
-            return [a for a in rd if a], [a for a in [acc(op.get('out')) if not (op.get('pw_out') or {}).get('buf') else None, acc(op.get('pw_out')), acc(op.get('out2')), acc(op.get('img_out')), acc(op.get('pack_out'))] if a]
+            return [a for a in rd if a], [a for a in [acc(op.get('out')) if not (op.get('pw_out') or {}).get('buf') else None, acc(op.get('pw_out')), acc(op.get('out2')), acc(op.get('img_out'))] if a]
 
         def hit(a, b):
             return a[0] == b[0] and a[1] < b[2] and b[1] < a[2]
@@ -372,7 +372,7 @@ def test_plan_interpreter_fused_ops_published_256(published_packed):
             plan = eng.plan(1, 256, 256)
             tags = [op['tag'] for op in plan['ops']]
             counts[fuse] = len(tags)
-            for mark in ('+pool', '+img', '+flows', '+resize2x', '+v=res+up', '+output_conv'):
+            for mark in ('+pool', '+misc16', '+resize2x', '+v=res+up', '+output_conv'):
                 assert any(mark in t for t in tags) == (fuse == 31), (fuse, mark)
             if fuse == 31:      # (an unfused plan is interpreted by test_plan_interpreter_matches_oracle_tiny[2-32-48])
                 arena = pi.run_plan(plan, layouts, x0, x1)
