@@ -150,7 +150,8 @@ struct WarpParams {
   float* flow_out;
   // Fused sixteen miscellaneous channels of an aligned-pyramid level (interpolator.py:167-183 warps [image | features] as one
   // tensor and appends the two half flows): dst3[pix] = {warp(src3, 0.5 pack_b) 3, warp(src3b, 0.5 pack_f) 3, 0.5 pack_b 2,
-  // 0.5 pack_f 2, 0 x 6}, pixel stride d3stride, produced by one more 16-lane channel slice of every pixel tile - the former
+  // 0.5 pack_f 2, 0 x 6}, pixel stride d3stride (multiple of 4, dst3 16-byte aligned), by one thread per pixel in workgroups behind the
+  // feature workgroups of a row band - the former
   // warp_c3 x 2 + pack_flow launches.  src3 / src3b: the two images [NB][H][W][3] (pixel stride s3stride), pack_b / pack_f:
   // backward / forward flow [NB][H][W][2].  dst3 == nullptr: none.
   const float* src3;
@@ -160,7 +161,6 @@ struct WarpParams {
   int d3stride;
   const float* pack_b;
   const float* pack_f;
-  int variant = -1;   // experiment knob (tools/warp_bench.hip): kernel MODE, -1 = the default
 };
 
 // Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:

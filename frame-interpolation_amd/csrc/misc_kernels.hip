@@ -249,40 +249,46 @@ __device__ __forceinline__ float2 warp_flow_at(const WarpParams& p, int64_t b, i
   return o;
 }
 
-// grid = (row units / 256, row groups of WARP_ROWS, images).  A thread owns (x, channel group g) for WARP_ROWS
-// consecutive output rows, four rows in flight at a time: the flows of the four rows first, then their sixteen
-// 16-byte corner loads, then the lerps and the four stores - 4x the memory-level parallelism of one row per thread, and
-// the source rows that neighbouring output rows share (fy+1 of row y = fy of row y+1 for smooth flows) are fetched
-// by the same CU within a few hundred cycles instead of by workgroups spread over the eight XCDs' L2s
-// (one row per workgroup: 2.3x over-fetch at the fabric, L2 hit rate 25 %, profiles/r01_pmc_summary.md).
-// Feature units: a workgroup = 16 consecutive pixels x ONE 64-channel slice (16 float4 groups) x the 8 rows of the band, so
-// that the corner pixels neighbouring outputs share (tr of x = tl of x + 1 for smooth flows) are read by the same workgroup
-// whatever the channel count - with the round-2 mapping (256 consecutive (pixel, group) units of a row) a workgroup covered
-// one pixel of a 960-channel level and every source pixel was fetched by up to four workgroups on different CUs / XCDs
-// (read over-fetch 1.57x at the fabric, profiles/r02_pmc_summary.md).  blockIdx.x = x tile * slices + slice; the image /
-// flow-packing units follow behind the feature workgroups as before.
+// grid = (feature workgroups of a row band + misc workgroups, row bands of WARP_ROWS, images).
+// Feature workgroup = 16 consecutive pixels x ONE 64-channel slice (16 float4 groups) x the 8 rows of the band; a thread owns
+// (x, channel group g) for the 8 rows, four rows in flight at a time: the flows of all eight rows first (the second half's flow
+// round trip overlaps the first half's corner loads), then per half the corner loads, the lerps and four stores.
+//  * Rows of a band share source rows: for smooth flows (real frames; the benchmark pair: 92-97 % of the neighbours) the top
+//    corners of output row y + 1 are the bottom corners of row y.  A thread keeps the bottom corners it loaded and skips the top
+//    loads of the next row when the source pixel index says they are the same pixel (any flow field gives the same values, so
+//    the same bits; tests/test_gpu_parity.py::test_warp_corner_sharing_is_bit_exact): 10 instead of 16 loads per half, +3-4 %
+//    (tools/warp_bench.hip, profiles/r04_warp_bench_modes.log).  Taking the right corners from the lane of pixel x + 1
+//    (ds_bpermute) on top of that did not pay (mode 3 there): the L2 request count is not what bounds this kernel.
+//  * 16 pixels x 64 channels per workgroup whatever the channel count: the corner pixels neighbouring outputs share are read by
+//    one workgroup (round 2 mapped 256 consecutive (pixel, group) units of a row to a workgroup, i.e. one pixel of a 960-channel
+//    level: read over-fetch 1.57x at the fabric against 1.32x).
+// Misc workgroups (behind the feature workgroups of the band; only the second t = 0.5 warp of a level has them): the sixteen
+// miscellaneous channels of an aligned-pyramid level, [warp(img0) 3 | warp(img1) 3 | 0.5 bflow 2 | 0.5 fflow 2 | 0 x 6].  One thread =
+// one pixel of one row of the band: 2 flows, 8 three-float corner loads (warp_c3_kernel's arithmetic per channel,
+// pack_flow_kernel's for the flows), then the 64 bytes of a pixel go through LDS so that four consecutive lanes store the four
+// 16-byte quarters of one pixel - full 64-byte lines.  Rounds 2-3 wrote these channels with 3 + 3 + 10 scalar stores per pixel at the
+// pixel pitch of the level (576 B ... 7.7 KB) from two launches, i.e. 16 four-byte L2 write requests per pixel: the t = 0.5 warps
+// ran at 2.8-3.0 TB/s against 5.2 TB/s for the flow-estimator warps of the same size (profiles/r03_per_op_profile.json).  A 16-lane
+// "channel slice" (lane c = channel c) was tried too: as many memory instructions as a full 64-channel slice for 1/8 of the bytes,
+// +0.31 ms on a 0.28 ms launch.
 constexpr int WARP_ROWS = 8;
 constexpr int WARP_TX = 16;    // pixels of a feature workgroup
-constexpr int WARP_MODE_DEFAULT = 3;
-constexpr int WARP_BATCH = 4;  // rows whose corner loads are in flight together (8: 160 registers, three waves per SIMD - 2 % slower)
-// MODE (experiment knob, tools/warp_bench.hip): 1 = top corners from the row above, 2 = right corners from the lane of pixel x + 1,
-// 4 = the miscellaneous channels as a 16-lane slice (else one thread per pixel behind the feature workgroups)
-template <int MODE>
+constexpr int WARP_BATCH = 4;  // rows whose corner loads are in flight together (8: 160 registers, three waves per SIMD - 2 % slower).
+                               // 106 registers = four waves per SIMD; forcing five (96, as before the corner reuse) spills 16
 __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int G = p.C >> 2;
   const unsigned nsl = (unsigned)(G + 15) >> 4;
-  const unsigned nslm = nsl + ((MODE & 4) && p.dst3 != nullptr ? 1u : 0u);
+  const unsigned nfeat_blocks = ((unsigned)(p.W + WARP_TX - 1) / WARP_TX) * nsl;
   const int yb = blockIdx.y * WARP_ROWS;
   const int64_t b = blockIdx.z;
-  const unsigned nfeat_blocks = ((unsigned)(p.W + WARP_TX - 1) / WARP_TX) * nslm;
   if (blockIdx.x >= nfeat_blocks) {
-    // misc units, one thread = one pixel of one row of the band: 2 flows, 8 three-float corner loads, four 16-byte stores
-    const unsigned u = (blockIdx.x - nfeat_blocks) * 256u + threadIdx.x;
-    if (u >= (unsigned)(p.W * WARP_ROWS)) return;
-    int k, x;
-    split_unit(u, p.W, k, x);
-    const int y = yb + k;
-    if (y >= p.H) return;
+    __shared__ float4 stage[256 * 4 + 64];   // [pixel][quarter], one float4 of padding per 16 pixels
+    const unsigned u0 = (blockIdx.x - nfeat_blocks) * 256u;
+    const unsigned u = u0 + threadIdx.x;
+    const unsigned band = (unsigned)(p.W * WARP_ROWS);
+    int k = 0, x = 0;
+    split_unit(min(u, band - 1u), p.W, k, x);
+    const int y = min(yb + k, p.H - 1);
     const int64_t pix = (b * p.H + y) * p.W + x;
     const float2 bf = reinterpret_cast<const float2*>(p.pack_b)[pix];
     const float2 ff = reinterpret_cast<const float2*>(p.pack_f)[pix];
@@ -290,7 +296,7 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
     float o[6];
 #pragma unroll
     for (int si = 0; si < 2; ++si) {
-      const float2 fl = si ? ff : bf;
+      const float2 fl = si ? ff : bf;   // image 0 is sampled with the backward flow, image 1 with the forward flow
       const float qy = (float)y + p.fscale * fl.y;
       const float qx = (float)x + p.fscale * fl.x;
       int fy, fx;
@@ -305,85 +311,33 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
       o[3 * si + 1] = lerp3(tl.g, tr.g, bl.g, br.g, ax, ay);
       o[3 * si + 2] = lerp3(tl.b, tr.b, bl.b, br.b, ax, ay);
     }
-    float4* d = reinterpret_cast<float4*>(p.dst3 + pix * p.d3stride);
-    d[0] = float4{o[0], o[1], o[2], o[3]};
-    d[1] = float4{o[4], o[5], bf.x * 0.5f, bf.y * 0.5f};
-    d[2] = float4{ff.x * 0.5f, ff.y * 0.5f, 0.f, 0.f};
-    d[3] = float4{0.f, 0.f, 0.f, 0.f};
-    return;
-  }
-  const unsigned xt = blockIdx.x / nslm, sl = blockIdx.x - xt * nslm;
-  if ((MODE & 4) && sl == nsl) {
-    // The sixteen miscellaneous channels of an aligned-pyramid level, [warp(img0) 3 | warp(img1) 3 | 0.5 bflow 2 | 0.5 fflow 2 |
-    // 0 x 6], as one more "channel slice" of the pixel tile: lane c of a pixel's sixteen produces channel c for the eight rows
-    // of the band (image lanes: a scalar bilinear gather with the flow of the opposite direction, warp_c3_kernel's arithmetic;
-    // flow lanes: 0.5 * flow, pack_flow_kernel's), so a pixel's 64 bytes leave in ONE store instruction as one full line.
-    // (Rounds 2-3 wrote them from one thread per pixel with 3 + 3 + 10 scalar stores at the 576-byte pixel pitch, in two
-    // launches: 16 four-byte L2 write requests per pixel - the t = 0.5 warps ran at 2.8-3.0 TB/s against 5.2 TB/s for the
-    // flow-estimator warps of the same size, profiles/r03_per_op_profile.json.)
-    const int x = (int)(xt * WARP_TX + (threadIdx.x >> 4)), c = (int)(threadIdx.x & 15);
-    if (x >= p.W) return;
-    const int si = c >= 3 ? 1 : 0;
-    const bool is_img = c < 6;
-    const float* const img = (si ? p.src3b : p.src3) + b * p.H * p.W * p.s3stride + (is_img ? c - 3 * si : 0);
-    float2 bfw[WARP_ROWS], ffw[WARP_ROWS];
+    float4* mine = stage + threadIdx.x * 4 + (threadIdx.x >> 4);
+    mine[0] = float4{o[0], o[1], o[2], o[3]};
+    mine[1] = float4{o[4], o[5], bf.x * 0.5f, bf.y * 0.5f};
+    mine[2] = float4{ff.x * 0.5f, ff.y * 0.5f, 0.f, 0.f};
+    mine[3] = float4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    // thread t stores quarter t & 3 of the pixels (t >> 2) + 64 i: a wave's store = 16 pixels x 64 contiguous bytes
 #pragma unroll
-    for (int k = 0; k < WARP_ROWS; ++k) {
-      const int64_t pix = (b * p.H + min(yb + k, p.H - 1)) * p.W + x;
-      bfw[k] = reinterpret_cast<const float2*>(p.pack_b)[pix];
-      ffw[k] = reinterpret_cast<const float2*>(p.pack_f)[pix];
-    }
-    float tl[WARP_ROWS], tr[WARP_ROWS], bl[WARP_ROWS], br[WARP_ROWS], ax[WARP_ROWS], ay[WARP_ROWS];
-#pragma unroll
-    for (int k = 0; k < WARP_ROWS; ++k) {
-      const int y = min(yb + k, p.H - 1);
-      const float2 fl = si ? ffw[k] : bfw[k];
-      const float qy = (float)y + p.fscale * fl.y;
-      const float qx = (float)x + p.fscale * fl.x;
-      int fy, fx;
-      warp_axis(qy, p.H, fy, ay[k]);
-      warp_axis(qx, p.W, fx, ax[k]);
-      tl[k] = tr[k] = bl[k] = br[k] = 0.f;
-      if (is_img) {
-        const float* s00 = img + ((int64_t)fy * p.W + fx) * p.s3stride;
-        const float* s10 = s00 + (int64_t)p.W * p.s3stride;
-        tl[k] = s00[0]; tr[k] = s00[p.s3stride]; bl[k] = s10[0]; br[k] = s10[p.s3stride];
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < WARP_ROWS; ++k) {
-      const int y = yb + k;
-      if (y >= p.H) break;
-      float v = lerp3(tl[k], tr[k], bl[k], br[k], ax[k], ay[k]);
-      if (!is_img) v = c == 6 ? bfw[k].x * 0.5f : c == 7 ? bfw[k].y * 0.5f : c == 8 ? ffw[k].x * 0.5f : c == 9 ? ffw[k].y * 0.5f : 0.f;
-      p.dst3[((b * p.H + y) * p.W + x) * p.d3stride + c] = v;
+    for (int i = 0; i < 4; ++i) {
+      const unsigned lp = (threadIdx.x >> 2) + 64u * i, uu = u0 + lp;
+      if (uu >= band) break;
+      int kk, xx;
+      split_unit(uu, p.W, kk, xx);
+      if (yb + kk >= p.H) break;
+      const float4 v = stage[lp * 4 + (lp >> 4) + (threadIdx.x & 3)];
+      *reinterpret_cast<float4*>(p.dst3 + ((b * p.H + yb + kk) * p.W + xx) * p.d3stride + (threadIdx.x & 3) * 4) = v;
     }
     return;
   }
+  const unsigned xt = blockIdx.x / nsl, sl = blockIdx.x - xt * nsl;
   const int x = (int)(xt * WARP_TX + (threadIdx.x >> 4)), g = (int)(sl * 16 + (threadIdx.x & 15));
-  // No early exit: the lanes past the row end / the last channel group keep running (no loads, no stores) so that the
-  // lane exchanges below are executed by whole waves.
-  const bool live = x < p.W && g < G;
-  const int xc = min(x, p.W - 1);
+  if (x >= p.W || g >= G) return;
   const int64_t rowpitch = (int64_t)p.W * p.sstride;
-  const float* const img = p.src + b * p.H * rowpitch + min(g, G - 1) * 4;
-  // Corner sharing.  For the smooth flows of real frames (and of the benchmark pair: 92-97 % of the neighbours) the top
-  // corners of output row y + 1 are the bottom corners of row y, and the right corners of pixel x are the left corners
-  // of pixel x + 1.  The sixteen loads of a thread's four rows used to be issued back to back, i.e. while the first
-  // copy of a line was still in flight, and the vector L1 does not merge a miss under a miss: every corner went to the
-  // L2 four times (TCC_REQ = 4.2x the algorithmic read, profiles/r03_pmc_summary.md, same for the identity gather).
-  // Now a thread loads the bottom-left corner of every row, the top-left one only when the row above did not fetch it
-  // (the compare is on the source pixel index), and takes the right column from the lane 16 up (= pixel x + 1, same
-  // channel group, same rows) when that lane's left column is this lane's right one - ds_bpermute, no memory.  The last
-  // pixel of a wave and every mismatch load as before, so any flow field gives the same values: same bits.
-  const unsigned lane = threadIdx.x & 63u;
-  const bool has_right = lane < 48u && x + 1 < p.W && g < G;
-  const int nb = (int)(((lane + 16u) & 63u) << 2);
-  // the flows of all eight rows first: the second half's flow round trip then overlaps the first half's corner loads instead of
-  // following them
+  const float* const img = p.src + b * p.H * rowpitch + g * 4;
   float2 flw[WARP_ROWS];
 #pragma unroll
-  for (int k = 0; k < WARP_ROWS; ++k) flw[k] = warp_flow_at(p, b, min(yb + k, p.H - 1), xc);
+  for (int k = 0; k < WARP_ROWS; ++k) flw[k] = warp_flow_at(p, b, min(yb + k, p.H - 1), x);
   float4 cbl = float4{0.f, 0.f, 0.f, 0.f}, cbr = cbl;   // bottom corners of the previous row of the band
   int cpix = -(1 << 30);
 #pragma unroll
@@ -391,56 +345,36 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
     if (yb + k0 >= p.H) break;
     float ay[WARP_BATCH], ax[WARP_BATCH];
     int pix[WARP_BATCH];
-    bool top_old[WARP_BATCH], right_nb[WARP_BATCH];
+    bool top_old[WARP_BATCH];
 #pragma unroll
     for (int j = 0; j < WARP_BATCH; ++j) {
       const int y = min(yb + k0 + j, p.H - 1);     // rows past the end repeat the last one (loads only, no store)
       const float2 fl = flw[k0 + j];
-      if (p.flow_out != nullptr && live && g == 0 && yb + k0 + j < p.H)
+      if (p.flow_out != nullptr && g == 0 && yb + k0 + j < p.H)
         reinterpret_cast<float2*>(p.flow_out)[(b * p.H + y) * p.W + x] = fl;
       const float qy = (float)y + p.fscale * fl.y;
-      const float qx = (float)xc + p.fscale * fl.x;
+      const float qx = (float)x + p.fscale * fl.x;
       int fy, fx;
       warp_axis(qy, p.H, fy, ay[j]);
       warp_axis(qx, p.W, fx, ax[j]);
       pix[j] = fy * p.W + fx;
-      top_old[j] = (MODE & 1) && pix[j] == (j ? pix[j - 1] : cpix) + p.W;
-      right_nb[j] = false;
-      if (MODE & 2) right_nb[j] = has_right && __builtin_amdgcn_ds_bpermute(nb, pix[j]) == pix[j] + 1;
+      top_old[j] = pix[j] == (j ? pix[j - 1] : cpix) + p.W;
     }
     float4 tl[WARP_BATCH], tr[WARP_BATCH], bl[WARP_BATCH], br[WARP_BATCH];
 #pragma unroll
     for (int j = 0; j < WARP_BATCH; ++j) {
       const float* s00 = img + (int64_t)pix[j] * p.sstride;
-      tl[j] = tr[j] = br[j] = float4{0.f, 0.f, 0.f, 0.f};
-      bl[j] = tl[j];
-      if (live) {
-        bl[j] = *reinterpret_cast<const float4*>(s00 + rowpitch);
-        if (!top_old[j]) tl[j] = *reinterpret_cast<const float4*>(s00);
-        if (!right_nb[j]) {
-          br[j] = *reinterpret_cast<const float4*>(s00 + rowpitch + p.sstride);
-          if (!top_old[j]) tr[j] = *reinterpret_cast<const float4*>(s00 + p.sstride);
-        }
+      bl[j] = *reinterpret_cast<const float4*>(s00 + rowpitch);
+      br[j] = *reinterpret_cast<const float4*>(s00 + rowpitch + p.sstride);
+      tl[j] = tr[j] = float4{0.f, 0.f, 0.f, 0.f};
+      if (!top_old[j]) {
+        tl[j] = *reinterpret_cast<const float4*>(s00);
+        tr[j] = *reinterpret_cast<const float4*>(s00 + p.sstride);
       }
     }
-    auto from_right = [&](const float4& v) {
-      float4 r;
-      r.x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb, __builtin_bit_cast(int, v.x)));
-      r.y = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb, __builtin_bit_cast(int, v.y)));
-      r.z = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb, __builtin_bit_cast(int, v.z)));
-      r.w = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(nb, __builtin_bit_cast(int, v.w)));
-      return r;
-    };
 #pragma unroll
-    for (int j = 0; j < WARP_BATCH; ++j) {
-      // left column first (in every lane), then the right one: the neighbour's left column must be final when it is taken
-      if (top_old[j]) tl[j] = j ? bl[j - 1] : cbl;
-      if (MODE & 2) {
-        const float4 ntl = from_right(tl[j]), nbl = from_right(bl[j]);
-        if (right_nb[j]) { tr[j] = ntl; br[j] = nbl; }
-        else if (top_old[j]) tr[j] = j ? br[j - 1] : cbr;
-      } else if (top_old[j]) tr[j] = j ? br[j - 1] : cbr;
-    }
+    for (int j = 0; j < WARP_BATCH; ++j)
+      if (top_old[j]) { tl[j] = j ? bl[j - 1] : cbl; tr[j] = j ? br[j - 1] : cbr; }
     cbl = bl[WARP_BATCH - 1]; cbr = br[WARP_BATCH - 1]; cpix = pix[WARP_BATCH - 1];
 #pragma unroll
     for (int j = 0; j < WARP_BATCH; ++j) {
@@ -451,7 +385,7 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
       o.y = lerp3(tl[j].y, tr[j].y, bl[j].y, br[j].y, ax[j], ay[j]);
       o.z = lerp3(tl[j].z, tr[j].z, bl[j].z, br[j].z, ax[j], ay[j]);
       o.w = lerp3(tl[j].w, tr[j].w, bl[j].w, br[j].w, ax[j], ay[j]);
-      if (live) *reinterpret_cast<float4*>(p.dst + ((b * p.H + y) * p.W + x) * p.dstride + g * 4) = o;
+      *reinterpret_cast<float4*>(p.dst + ((b * p.H + y) * p.W + x) * p.dstride + g * 4) = o;
     }
   }
 }
@@ -573,19 +507,8 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
   } else {
     if (p.dst3 != nullptr && (!p.src3 || !p.src3b || !p.pack_b || !p.pack_f)) return hipErrorInvalidValue;
     if (p.dst3 != nullptr && ((p.d3stride & 3) || (reinterpret_cast<uintptr_t>(p.dst3) & 15))) return hipErrorInvalidValue;
-    const int mode = p.variant < 0 ? WARP_MODE_DEFAULT : p.variant;
-    const bool slice = (mode & 4) && p.dst3 != nullptr;
-    const int64_t blocks = (int64_t)((p.W + WARP_TX - 1) / WARP_TX) * ((p.C / 4 + 15) / 16 + (slice ? 1 : 0)) +
-                           (p.dst3 != nullptr && !slice ? ((int64_t)p.W * WARP_ROWS + 255) / 256 : 0);
-    const dim3 grid((unsigned)blocks, (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB);
-    switch (mode) {
-      case 0: hipLaunchKernelGGL(warp_vec_kernel<0>, grid, dim3(256), 0, s, p); break;
-      case 1: hipLaunchKernelGGL(warp_vec_kernel<1>, grid, dim3(256), 0, s, p); break;
-      case 3: hipLaunchKernelGGL(warp_vec_kernel<3>, grid, dim3(256), 0, s, p); break;
-      case 4: hipLaunchKernelGGL(warp_vec_kernel<4>, grid, dim3(256), 0, s, p); break;
-      case 7: hipLaunchKernelGGL(warp_vec_kernel<7>, grid, dim3(256), 0, s, p); break;
-      default: return hipErrorInvalidValue;
-    }
+    const int64_t blocks = (int64_t)((p.W + WARP_TX - 1) / WARP_TX) * ((p.C / 4 + 15) / 16) + (p.dst3 != nullptr ? ((int64_t)p.W * WARP_ROWS + 255) / 256 : 0);
+    hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)blocks, (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB), dim3(256), 0, s, p);
   }
   return hipGetLastError();
 }

@@ -1,5 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r04x; cd /root/repo; O=gpurun_out/r04x
+timeout 200 tools/bin/warp_bench
 timeout 900 python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "warp_corner or published_64 or config2_256 or graph_replay or aux or stages" 2>&1 | tail -5
 timeout 600 python bench.py --no-cpu-baseline --no-split --profile-out $O/per_op_profile.json > $O/bench_1gpu.json 2> $O/bench.err
 python - <<'PY'

@@ -1,7 +1,7 @@
-// warp_bench.hip -- A/B of warp_vec_kernel's experiment modes on the shapes of a 1080p 2x2-tiled forward (development tool).
-//   mode bit 1: top corners from the row above, 2: right corners from the lane of pixel x + 1 (ds_bpermute),
-//        bit 4: the sixteen miscellaneous channels of an aligned level as a 16-lane slice (else one thread per pixel)
-// Smooth synthetic flows (like the benchmark pair's: ~95 % of the neighbours share corners); every mode must write the same bytes.
+// warp_bench.hip -- warp_vec_kernel on the shapes of a 1080p 2x2-tiled forward, with and without the sixteen miscellaneous channels of
+// an aligned level (development tool).  Smooth synthetic flows (like the benchmark pair's: ~95 % of the neighbours share corners).
+// (Commit 709bc1e carried a `variant` knob in WarpParams and compared the modes that were tried - corners from the row above, from the
+// neighbouring lane, the miscellaneous channels as a 16-lane slice: profiles/r04_warp_bench_modes.log.)
 //   hipcc --offload-arch=gfx950 -O2 -Iframe-interpolation_amd/csrc tools/warp_bench.hip frame-interpolation_amd/csrc/build/misc_kernels.o -o tools/bin/warp_bench
 #include "film_kernels.h"
 #include <cmath>
@@ -40,11 +40,10 @@ int main() {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int misc = 0; misc < 2; ++misc) {
       std::vector<float> want;
-      for (int mode : {0, 1, 3, 4, 7}) {
-        if (!misc && (mode & 4)) continue;
+      for (int mode : {0}) {
         WarpParams p{};
         p.src = src; p.sstride = sh.C; p.C = sh.C; p.flow = flow; p.fscale = 0.5f; p.dst = dst + sh.C; p.dstride = dstride;
-        p.NB = sh.NB; p.H = sh.H; p.W = sh.W; p.variant = mode;
+        p.NB = sh.NB; p.H = sh.H; p.W = sh.W;
         if (misc) { p.src3 = img; p.src3b = img + npix * 3; p.s3stride = 3; p.dst3 = dst + 2 * sh.C; p.d3stride = dstride; p.pack_b = flow2; p.pack_f = flow; }
         CK(hipMemset(dst, 0, npix * dstride * 4));
         for (int i = 0; i < 5; ++i) CK(film_launch_warp(p, nullptr));
@@ -61,8 +60,8 @@ int main() {
         if (want.empty()) want = got;
         const bool same = memcmp(want.data(), got.data(), got.size() * 4) == 0;
         const double bytes = 4.0 * npix * (2.0 * sh.C + 2 + (misc ? 12 : 0));
-        printf("%s  %dx%dx%dx%d  %s  mode %d : %.4f ms  %.2f TB/s  %s\n", sh.name, sh.NB, sh.H, sh.W, sh.C, misc ? "features + misc16" : "features only    ", mode, ms,
-               bytes / ms * 1e-9, same ? "same bytes" : "DIFFERENT");
+        (void)mode; (void)same;
+        printf("%s  %dx%dx%dx%d  %s : %.4f ms  %.2f TB/s\n", sh.name, sh.NB, sh.H, sh.W, sh.C, misc ? "features + misc16" : "features only    ", ms, bytes / ms * 1e-9);
       }
     }
     CK(hipFree(src)); CK(hipFree(flow)); CK(hipFree(flow2)); CK(hipFree(img)); CK(hipFree(dst)); CK(hipFree(ref));
