@@ -509,6 +509,15 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->opt_fold = value != 0;
     }
   }
+  else if (!strcmp(key, "planar")) {
+    if ((value != 0) != (h->opt_planar != 0)) {  // plans carry the buffer layout: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_planar = value != 0;
+    }
+  }
   else if (!strcmp(key, "winograd")) {
     if (value < 0 || value > 3) return fail(h, FILM_ERR_INVALID, "winograd: 0, 1, 2 or 3");
     if ((int)value != h->opt_wino) {  // plans carry the kernel choice: drop them
@@ -916,7 +925,22 @@ int film_get_tap(film_t* h, const char* name, float* dst, int64_t cap, int64_t d
   if (cap < b.size()) return fail(h, FILM_ERR_INVALID, "capacity %lld < %lld floats", (long long)cap, (long long)b.size());
   HIPCHK(h, hipSetDevice(h->device));
   HIPCHK(h, hipDeviceSynchronize());
-  HIPCHK(h, hipMemcpy(dst, P->arena + b.off, (size_t)b.size() * sizeof(float), hipMemcpyDeviceToHost));
+  if (!b.planar) {
+    HIPCHK(h, hipMemcpy(dst, P->arena + b.off, (size_t)b.size() * sizeof(float), hipMemcpyDeviceToHost));
+    return FILM_OK;
+  }
+  // three pixel-major planes -> [N][H][W][C]
+  std::vector<float> raw((size_t)b.size());
+  HIPCHK(h, hipMemcpy(raw.data(), P->arena + b.off, raw.size() * sizeof(float), hipMemcpyDeviceToHost));
+  const int64_t npix = (int64_t)b.N * b.H * b.W;
+  const int pc[3] = {b.planar, b.planar, b.C - 2 * b.planar};
+  int64_t base = 0;
+  int coff = 0;
+  for (int part = 0; part < 3; ++part) {
+    for (int64_t i = 0; i < npix; ++i) std::memcpy(dst + i * b.C + coff, raw.data() + base + i * pc[part], (size_t)pc[part] * sizeof(float));
+    base += npix * pc[part];
+    coff += pc[part];
+  }
   return FILM_OK;
 }
 

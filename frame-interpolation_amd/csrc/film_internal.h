@@ -39,6 +39,9 @@ struct Buffer {
   int64_t off;  // floats from arena base
   int N, H, W, C;      // all 0 for scratch regions (reinterpreted per use)
   int64_t floats;      // extent
+  // > 0: the buffer is stored as three pixel-major planes, [N][H][W][planar] x 2 then [N][H][W][C - 2 planar], instead of
+  // [N][H][W][C] (the aligned pyramid levels: each plane is written contiguously by one warp launch; film_get_tap interleaves)
+  int planar = 0;
   int64_t size() const { return floats; }
 };
 
@@ -181,6 +184,7 @@ struct film_handle {
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
   int opt_fuse = 31;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
+  int opt_planar = 1;     // 1: aligned-pyramid levels as three planes (feat0 | feat1 | misc16), each written contiguously by its warp
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)

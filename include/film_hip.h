@@ -157,8 +157,8 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  copy, 4 + bf16 split copies (normally packed on demand)
  *   "fuse"    bits 31 (default): small-launch fusion, identical arithmetic and bit-identical results.  1: tf.image.resize(2 * v)
  *                  of the flow estimator inside the warp kernels that consume it; 2: v = residual + upsampled flow inside
- *                  the flow-head kernels; 4: the 3-channel image warps of the t = 0.5 stage inside the feature warps of the
- *                  same flow; 8: AveragePooling2D of the sub-extractor
+ *                  the flow-head kernels; 4: the warped images and the half flows of the t = 0.5 stage (the sixteen miscellaneous
+ *                  channels of an aligned level) inside the second feature warp of the level; 8: AveragePooling2D of the sub-extractor
  *                  stages in the epilogue of the F(4,3) convolution in front of it (about 35 launches fewer per forward in all);
  *                  16: the RGB head (1x1 convolution, fusion.py:138-140) in the epilogue of the last decoder layer, whose
  *                  64-channel output is then never written.  0: one launch per reference op.  Drops the cached plans.
@@ -166,6 +166,11 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  sub-pixel phase convolutions on the low-resolution input with pre-summed weights (9 taps per 4
  *                  outputs instead of 16; an exact regrouping of the sum, rounding differs at the 1e-7 level).
  *                  0: one 2x2 convolution with the upsample folded into its gather.  Drops the cached plans.
+ *   "planar" 0/1   1 (default): an aligned-pyramid level (interpolator.py:167-183) is stored as three pixel-major planes -
+ *                  warp(features of image 0), warp(features of image 1), the sixteen image / flow channels - each written
+ *                  contiguously by its warp, and read by the decoder as three input segments in the reference's channel
+ *                  order (same weights, same sums, same bits); film_get_tap("aligned<l>") interleaves them.  0: one
+ *                  [N][H][W][2C + 16] buffer per level.  Drops the cached plans.
  *   "winograd" w   1 (default): the large 3x3 convolutions use a 1-D Winograd transform along x - F(4,3) (2x fewer
  *                  fp32 multiplies, 128-pixel patches) on the levels whose width fills its patches, F(2,3) (1.5x fewer)
  *                  elsewhere; fp32 throughout, the rounding differs from the direct sum at the 1e-6 (F(2,3)) /

@@ -235,7 +235,15 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
 
 def tap(plan: dict, arena: np.ndarray, name: str) -> np.ndarray:
     b = next(x for x in plan['buffers'] if x['name'] == name)
-    return arena[b['off']:b['off'] + b['floats']].reshape(b['N'], b['H'], b['W'], b['C']).copy()
+    raw = arena[b['off']:b['off'] + b['floats']]
+    if not b.get('planar'):
+        return raw.reshape(b['N'], b['H'], b['W'], b['C']).copy()
+    # three pixel-major planes (aligned-pyramid levels) -> [N, H, W, C], as film_get_tap returns them
+    npix, parts, base = b['N'] * b['H'] * b['W'], [], 0
+    for c in (b['planar'], b['planar'], b['C'] - 2 * b['planar']):
+        parts.append(raw[base:base + npix * c].reshape(b['N'], b['H'], b['W'], c))
+        base += npix * c
+    return np.concatenate(parts, axis=-1)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -497,21 +497,29 @@ def _warp_numpy(src, flow, fscale):
     return ay * (bot - top) + top
 
 
+@pytest.mark.parametrize('planar', [1, 0])
 @pytest.mark.parametrize('b,h,w', [(1, 64, 64), (2, 192, 320), (1, 320, 448), (1, 576, 960)])
-def test_warp_corner_sharing_is_bit_exact(published, b, h, w):
+def test_warp_corner_sharing_is_bit_exact(published, b, h, w, planar):
     """warp_vec_kernel takes a corner from the row above / the lane of pixel x + 1 when the source pixel indices say it
     is the same pixel, and loads it otherwise: every t = 0.5 feature and image warp of a forward (flows of the network
     itself: mostly shared corners, some not; rows that end inside a 16-pixel workgroup; levels down to 4x4) must have
-    exactly the bits of the gather computed in numpy from the engine's own feature / image / flow taps."""
+    exactly the bits of the gather computed in numpy from the engine's own feature / image / flow taps - with the aligned
+    levels stored as three planes (default) and interleaved, and the image itself has the same bits either way."""
     from film_hip import weights as W
     from film_hip.engine import FilmEngine
     opt, wts, _ = published
     eng = FilmEngine(opt, device=0)
     eng.set_weights(wts)
+    eng.set_option('planar', planar)
     rng = np.random.default_rng(h * w)
     x0 = rng.random((b, h, w, 3), dtype=np.float32)
     x1 = np.roll(x0, (2, -3), axis=(1, 2)) + rng.normal(0, 0.02, x0.shape).astype(np.float32)
-    eng.forward(x0, x1)
+    image = eng.forward(x0, x1)
+    if planar == 0 and (b, h, w) != (1, 576, 960):
+        other = FilmEngine(opt, device=0)
+        other.set_weights(wts)
+        assert np.array_equal(other.forward(x0, x1), image)
+        other.close()
     fc = W.feature_channels(opt)
     shared = []
     for l in range(opt.fusion_pyramid_levels):
