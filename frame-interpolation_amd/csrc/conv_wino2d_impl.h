@@ -53,7 +53,8 @@ enum { W2D_F_XFIRST = 32,      // tools only: x transform per row, then the y co
        W2D_DBG_NOBAR = 2048,   // no barrier in the K loop
        W2D_DBG_NORD = 4096,    // no fragment reads in the K loop
        W2D_DBG_TIME = 8192 };  // wave 0 of every workgroup writes s_memtime at kernel entry / first MFMA / last MFMA / exit to
-                               // p.part[workgroup * 8 ..] (tools/w2d_bench.hip prints the averages)
+                               // p.part[workgroup * 8 ..], and behind the first DMA request / its own stage-0 share / the first barrier
+                               // (tools/w2d_bench.hip prints the averages)
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the MFMA gaps of a chunk, every index a compile-time constant
 template <class F, int... G>
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int l31 = lane & 31, half = lane >> 5;
   const int mu = wv & 3, ng = wv >> 2;
 
-  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0;
+  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tmA = 0, tmB = 0, tmC = 0;
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm0 = __builtin_readcyclecounter();
 
   int bx = blockIdx.x, by = blockIdx.y;
@@ -114,7 +115,26 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   int rsg = 0, rc0 = 0, rsegC = 0;
   conv_rsrc_t rrsrc = conv_make_rsrc(uniform_ptr(p.seg[0].ptr));
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
-  auto raw_setup_seg = [&]() {   // (once per input segment: the lane's slots are re-derived here rather than kept in registers)
+  // Which (halo row, pixel, 16-byte piece) a lane's slot is, and whether that pixel lies in the image, does not depend on the input
+  // segment: (pixel offset from the first halo row) << 2 | piece, or ~0 for padding / outside ('same' padding = zeros), once per
+  // workgroup - the three divisions per request used to be redone for every segment set-up, inlined at four places (a third of the
+  // 1 190 instructions in front of the first MFMA; two waves per SIMD issue those at ~8 cycles each: the prologue is issue bound).
+  unsigned rpk[IPW];
+  {
+    const int H = p.H, W = p.W;
+#pragma unroll
+    for (int n = 0; n < IPW; ++n) {
+      const int sl = 64 * (wv + NW * n) + lane;
+      const int r = sl / RP4, rem = sl - r * RP4;
+      const int m = rem / MO4, rr = rem - m * MO4;
+      const int c = rr / CO4, k = rr - c * CO4;
+      const int px = 4 * k + m;
+      const int y = y0 - 1 + r, x = x0 - 1 + px;
+      const bool ok = r < HR && rem < 4 * MO4 && px < PW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;   // else padding / outside the image
+      rpk[n] = ok ? (unsigned)(r * W + x) << 2 | (unsigned)c : OOB;
+    }
+  }
+  auto raw_setup_seg = [&]() {
     const ConvSeg& s = p.seg[rsg];
     rsegC = __builtin_amdgcn_readfirstlane(s.C);
     int be = img + s.boff;
@@ -122,20 +142,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     // (the finished pointer through readfirstlane: should hipcc ever reload `p` with vector loads - it does behind an atomic - a buffer
     // resource in VGPRs cannot feed the DMA statement - nor a buffer load without a waterfall loop)
     rrsrc = conv_make_rsrc(uniform_ptr(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride));
-    int ln = lane;
-    asm volatile("" : "+v"(ln));   // opaque: keeps the slot arithmetic below out of the K loop's live registers
+    const unsigned st4 = (unsigned)s.stride * 4u;
 #pragma unroll
-    for (int n = 0; n < IPW; ++n) {
-      const int sl = 64 * (wv + NW * n) + ln;
-      const int r = sl / RP4, rem = sl - r * RP4;
-      const int m = rem / MO4, rr = rem - m * MO4;
-      const int c = rr / CO4, k = rr - c * CO4;
-      const int px = 4 * k + m;
-      const int y = y0 - 1 + r, x = x0 - 1 + px;
-      const bool ok = r < HR && rem < 4 * MO4 && px < PW && y >= 0 && y < p.H && x >= 0 && x < p.W;   // else padding / outside the image
-      rvoff[n] = ok ? (unsigned)((r * p.W + x) * s.stride + c * 4) * 4u : OOB;
-      asm volatile("" : "+v"(rvoff[n]));
-    }
+    for (int n = 0; n < IPW; ++n) rvoff[n] = rpk[n] == OOB ? OOB : (rpk[n] >> 2) * st4 + (rpk[n] & 3u) * 16u;
   };
   auto dma_piece = [&](int n, int stage) {   // request n of this wave's share of the cursor's super-chunk -> stage
     const unsigned so = (unsigned)rc0 * 4u;
@@ -256,6 +265,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // ---- prologue ------------------------------------------------------------------------------------------------------------
   raw_setup_seg();
   raw_issue(0);
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmA = __builtin_readcyclecounter();
 #pragma unroll
   for (int set = 0; set < 2; ++set)
 #pragma unroll
@@ -268,7 +278,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   if (nsc > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + 2 * IPW) : "memory");
   else if (nsc > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + IPW) : "memory");
   else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmB = __builtin_readcyclecounter();
   __syncthreads();
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmC = __builtin_readcyclecounter();
   prepare(A[0], 0, C0{});
 
   // ---- K loop: chunk kc = (super-chunk s, half h).  Super-chunk s lives in stage s % 3; chunk kc prepares the fragments of chunk
@@ -497,7 +509,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const unsigned long long tm3 = __builtin_readcyclecounter();
     if (t == 0) {
       unsigned long long* o8 = reinterpret_cast<unsigned long long*>(p.part) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
-      o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3;
+      o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3; o8[4] = tmA; o8[5] = tmB; o8[6] = tmC;
     }
   }
 }

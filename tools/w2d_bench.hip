@@ -252,15 +252,16 @@ int main(int argc, char** argv) {
         const size_t nwg = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / v.bn);
         std::vector<unsigned long long> tm(nwg * 8);
         CK(hipMemcpy(tm.data(), d_tm, nwg * 64, hipMemcpyDeviceToHost));
-        double pro = 0, loop = 0, epi = 0;
+        double pro = 0, loop = 0, epi = 0, pa = 0, pb = 0, pc = 0;
         unsigned long long tmin = ~0ull, tmax = 0;
         for (size_t i = 0; i < nwg; ++i) {
+          pa += (double)(tm[i * 8 + 4] - tm[i * 8]); pb += (double)(tm[i * 8 + 5] - tm[i * 8 + 4]); pc += (double)(tm[i * 8 + 6] - tm[i * 8 + 5]);
           pro += (double)(tm[i * 8 + 1] - tm[i * 8]); loop += (double)(tm[i * 8 + 2] - tm[i * 8 + 1]); epi += (double)(tm[i * 8 + 3] - tm[i * 8 + 2]);
           if (tm[i * 8] < tmin) tmin = tm[i * 8];
           if (tm[i * 8 + 3] > tmax) tmax = tm[i * 8 + 3];
         }
-        printf("   [time] %zu workgroups: prologue %.0f  K loop %.0f  epilogue %.0f ticks (averages); kernel span %llu ticks; ids of wg 0: hw_id %llx xcc %llx\n", nwg,
-               pro / nwg, loop / nwg, epi / nwg, tmax - tmin, tm[4], tm[5]);
+        printf("   [time] %zu workgroups: prologue %.0f (entry -> first DMA issued %.0f, -> stage 0 landed %.0f, -> barrier passed %.0f, -> fragments of chunk 0 ready)  K loop %.0f  epilogue %.0f cycles (averages); kernel span %llu\n", nwg,
+               pro / nwg, pa / nwg, pb / nwg, pc / nwg, loop / nwg, epi / nwg, tmax - tmin);
         // busy share of one CU slot: follow the workgroups that ran on the CU of workgroup 0 (same hw_id CU/SE bits and XCC)
       }
       const bool abl = v.fam < 0;
