@@ -2,7 +2,7 @@
 //
 // Same mapping as conv_igemm_impl.h (M = output pixels, N = Cout, K walked in 16-channel steps over
 // (tap, concat segment, chunk); fp32 v_mfma_f32_32x32x2_f32; bias + leaky_relu epilogue).  Measured on MI355X
-// (tools/conv_bench.hip + rocprofv3 PMC): every non-MFMA vector instruction issued inside the K loop costs
+// (tools/retired/conv_bench.hip + rocprofv3 PMC): every non-MFMA vector instruction issued inside the K loop costs
 // matrix-pipe time that the co-resident waves do not win back, while the memory system is nowhere near a limit
 // (gathers from one pixel run exactly as fast).  So this kernel spends no VALU instruction per K-step:
 //

@@ -22,7 +22,7 @@
 //                      LDS traffic and MFMAs.
 //   conv_igemm_impl.h  the first-generation kernel (64-bit pointers, select-based zero fill, [K][N] weights);
 //                      still runs the 3-channel first layer (its 4-taps-per-step mode) and is the A/B baseline
-//                      of tools/conv_bench.hip.
+//                      of tools/retired/conv_bench.hip.
 #include "conv_buf_impl.h"
 #include "conv_halo_impl.h"
 #include "conv_split_impl.h"

@@ -1,6 +1,6 @@
 // conv_igemm_impl.h -- the implicit-GEMM convolution kernel template (see conv_igemm.hip for the overview).
 // Round 1's general kernel.  What still uses it: the first-layer (3-channel, [48][Cout] weights) mode for Cout other than 32 / 64
-// (conv_c3_kernel covers those two), and tools/conv_bench.hip as the A/B baseline; every other layer runs conv_buf_kernel or one of
+// (conv_c3_kernel covers those two), and tools/retired/conv_bench.hip as the A/B baseline; every other layer runs conv_buf_kernel or one of
 // the Winograd kernels.
 //
 // Template knobs (all compile time):
@@ -21,7 +21,7 @@ enum : int {
   CONV_F_C3 = 8,         // first layer (feature_extractor.py:119-120): the single segment is the 3-channel image
                          // (stride 3); K = 12 tap slots x 4 (3 channels + one zero), i.e. 3 steps of 4 taps; the
                          // weights are packed [48][Cout] with row = tap*4 + channel (zero rows for the padding)
-  // ablation switches for tools/conv_bench.hip only (results are wrong on purpose):
+  // ablation switches for tools/retired/conv_bench.hip only (results are wrong on purpose):
   CONV_F_DBG_NOGLOBAL = 64,   // no global loads / LDS stores inside the K loop
   CONV_F_DBG_NOLDSREAD = 128, // no LDS fragment reads inside the K loop (operands from registers)
   CONV_F_DBG_NOBARRIER = 256, // no barrier inside the K loop

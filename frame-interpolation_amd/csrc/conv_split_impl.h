@@ -8,7 +8,7 @@
 //                                                                         (worst case 2^-15; measured rms 4.4e-6, mean 1e-9: zero mean)
 // Six (three) bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64 cycles per 16 K: 2.67x (5.3x) the matrix
 // rate.  bf16x6 is fp32-level accurate (max |delta| 2.8e-5 on outputs of O(10) against the fp32 kernels,
-// tools/conv_bench.hip: the same as between two fp32 kernels that sum K in a different order); bf16x3 stages only
+// tools/retired/conv_bench.hip: the same as between two fp32 kernels that sum K in a different order); bf16x3 stages only
 // the hi and mid planes (2/3 of the LDS and of the split VALU work).  Measured speed of bf16x6: 1.45-1.65x - at
 // 68 % MFMA-pipe occupancy the bf16 matrix pipe is power limited (clock 1.9 GHz), like every dense bf16 GEMM on
 // this part.

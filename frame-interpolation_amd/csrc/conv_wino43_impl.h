@@ -34,23 +34,13 @@
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W43_F_SETPRIO = 64,     // FLAGS bit (experiments): raise the wave priority around the MFMA groups (measured: -1..-3 %)
-       // timing ablations (tools/conv_bench.hip only; results are wrong on purpose):
-       W43_DBG_NOA = 256,      // no activation loads / transforms / LDS stores inside the K loop
-       W43_DBG_NOB = 512,      // no weight loads / LDS stores inside the K loop
-       W43_DBG_NOBAR = 1024,   // no barrier inside the K loop
-       W43_DBG_NOFRAG = 2048,
-       W43_DBG_NOALOAD = 4096, // activation loads skipped, transform + LDS stores of stale registers kept
-       W43_DBG_NOASTORE = 8192,// activation loads kept, transform + LDS stores skipped
-       W43_DBG_OLDLOOP = 16384,// (A/B in tools/conv_bench.hip) the PF2 K loop with the odd chunk under a condition, as before round 3
-       W43_F_PF2 = 32768,      // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
-       W43_F_PERSIST = 524288, // the pair loop exists (ConvParams::persist launches need it; without it a workgroup runs ONE pair and the
-                               // code is the straight-line kernel: the loop costs the 128-register tile its four workgroups per CU)
-       W43_F_PRE1 = 131072,    // persistent launches: the next pair's first activation chunk is requested in front of the epilogue
-       W43_F_PRE2 = 262144,    // ... and so is the rest of its prologue (weight stages, PF2's second chunk): 84 more live registers
+enum { W43_F_PF2 = 32768,      // activation loads requested TWO chunks ahead (second register set): ~4 stages of load-to-use distance
        W43_F_BG = 65536 };     // weight fragments straight from global memory (L1 / L2) into registers, requested two stages
                                // ahead: no weight ring in LDS (36 KB instead of 54 KB for the 32-channel tile = FOUR workgroups
                                // per CU), no weight stores, two barriers per chunk instead of three
+// (Rounds 2-3 carried experiment flags here - wave priorities around the MFMA groups (-1..-3 %), persistent workgroups that request
+// the next pair's loads in front of the epilogue (no gain), timing ablations - driven by tools/retired/conv_bench.hip; their
+// measurements are in DESIGN.md 9 and profiles/r0[23]_*; the code went with round 4.)
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
 __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & W43_F_BG) != 0 && BN == 32 && QW <= 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
@@ -84,16 +74,11 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   const int h = wv / PW, pw = wv % PW;     // nu half, pair-wave
   const int rg = pw / NG, ng = pw % NG;
 
-  // ---- the (patch, channel block) pairs of this workgroup: lin, lin + stride, ... of the NB * ntx * nty * (Cout / BN) pairs.
-  // A launch with one workgroup per pair has stride == total (the loop at the bottom runs once); a PERSISTENT launch
-  // (ConvParams::persist workgroups per K split, grid.y = 1) walks several per workgroup and requests the first loads of
-  // the next pair IN FRONT OF the epilogue of the current one, so that the fixed cost of a pair - three K chunks' worth of
-  // load latency, exchange and 64 KB of stores - overlaps inside the workgroup as well as across the workgroups of a CU.
+  // ---- the (patch, channel block) pair of this workgroup, one of the NB * ntx * nty * (Cout / BN) pairs ------------------------
   const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
   const int nbx = p.NB * ntx * nty, nby = p.Cout / BN;
   const int total = nbx * nby;
-  const int stride = (int)(gridDim.x * gridDim.y);
-  int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
+  const int lin = (int)(blockIdx.y * gridDim.x + blockIdx.x);
   int img = 0, y0 = 0, x0 = 0, n0 = 0;
   auto decode = [&](int l) {
     int bx, by;
@@ -265,8 +250,7 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   begin_pair_a();
   begin_pair_b();
 
-  while (true) {
-  const int cimg = img, cy0 = y0, cx0 = x0, cn0 = n0;   // the pair the accumulators below belong to (img .. n0 move on early)
+  const int cimg = img, cy0 = y0, cx0 = x0, cn0 = n0;
   f32x16 acc[TM][NU][TN];   // [row][nu - NU*h][channel tile]
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -288,11 +272,9 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   const int b_ad = 2 * A_STAGE4 + (NU * h) * B_PLANE4 + (ng * TN * 32 + l31) * 2 + (half ^ swb);
   int a_cur = a_ad;
 
-  bool in_loop = false;
   bf4 fa[3][TM], fb[3][TN];   // [nu step j mod 3][tile]: triple buffered
   auto fetch = [&](auto dy_c, auto j_c, int a_base) {
     constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
-    if constexpr ((FLAGS & W43_DBG_NOFRAG) != 0) { if (in_loop) return; }
     const int ab = (QW == 8 && (DY & 1)) ? (a_base ^ 1) : a_base;
 #pragma unroll
     for (int mt = 0; mt < TM; ++mt) fa[J % 3][mt] = smem4[ab + ((mt * RPT + DY) * 6 + J) * (QW * 2)];
@@ -303,7 +285,6 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   };
   auto compute = [&](auto dy_c, auto j_c) {
     constexpr int DY = decltype(dy_c)::value, J = decltype(j_c)::value;
-    if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -311,7 +292,6 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
 #pragma unroll
         for (int nt = 0; nt < TN; ++nt)
           acc[mt][J][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[J % 3][mt][k], BG ? fbg[BG ? DY : 0][BG ? J : 0][nt][k] : fb[J % 3][nt][k], acc[mt][J][nt], 0, 0, 0);
-    if constexpr ((FLAGS & W43_F_SETPRIO) != 0) __builtin_amdgcn_s_setprio(0);
   };
 
   // ---- pipeline ----------------------------------------------------------------------------------------------------------
@@ -325,11 +305,6 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   __syncthreads();
   fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, a_cur);
   int a_stage = 0;
-  if constexpr ((FLAGS & W43_DBG_NOFRAG) != 0) {
-    fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, a_cur);
-    fetch(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, a_cur);
-    in_loop = true;
-  }
   // one K chunk; PAR = parity of kc (PF2: the register set that receives chunk kc + 2 and held chunk kc)
   auto chunk = [&](int kc, auto par_c) {
     constexpr int PAR = decltype(par_c)::value;
@@ -338,8 +313,8 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
     auto stage = [&](auto dy_c) {
       constexpr int DY = decltype(dy_c)::value;
       if constexpr (BG) load_bg(s0 + DY + 2, std::integral_constant<int, (DY + 2) % 3>{});
-      else if constexpr ((FLAGS & W43_DBG_NOB) == 0) load_b(s0 + DY + 3, DY);
-      if constexpr (DY == 0 && (FLAGS & (W43_DBG_NOA | W43_DBG_NOALOAD)) == 0) load_item(std::integral_constant<int, PF2 ? PAR : 0>{});
+      else load_b(s0 + DY + 3, DY);
+      if constexpr (DY == 0) load_item(std::integral_constant<int, PF2 ? PAR : 0>{});
       fetch(dy_c, std::integral_constant<int, 1>{}, a_cur);
       compute(dy_c, std::integral_constant<int, 0>{});
       fetch(dy_c, std::integral_constant<int, 2>{}, a_cur);
@@ -355,12 +330,12 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       fetch(std::integral_constant<int, (DY + 1) % 3>{}, std::integral_constant<int, 0>{}, DY == 2 ? a_next : a_cur);
       compute(dy_c, std::integral_constant<int, NU - 1>{});
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (!BG && (FLAGS & W43_DBG_NOB) == 0) store_b((DY + 2) % 3, (DY + 2) % 3);
-      if constexpr (DY == 1 && (FLAGS & (W43_DBG_NOA | W43_DBG_NOASTORE)) == 0) store_item(a_stage ^ 1, std::integral_constant<int, PF2 ? 1 - PAR : 0>{});
+      if constexpr (!BG) store_b((DY + 2) % 3, (DY + 2) % 3);
+      if constexpr (DY == 1) store_item(a_stage ^ 1, std::integral_constant<int, PF2 ? 1 - PAR : 0>{});
       // BG: only the activation double buffer is shared.  It is written in the dy = 1 stage: the barrier of dy = 0 puts every
       // wave's reads of the previous chunk in front of that write, the barrier of dy = 1 puts the write in front of the
       // first read (the fragment prefetch at the end of dy = 2)
-      if constexpr ((FLAGS & W43_DBG_NOBAR) == 0 && (!BG || DY != 2)) __syncthreads();
+      if constexpr (!BG || DY != 2) __syncthreads();
     };
     stage(std::integral_constant<int, 0>{});
     stage(std::integral_constant<int, 1>{});
@@ -372,36 +347,17 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
   if constexpr (PF2) {
     // unconditional pairs + a peeled last chunk: with `if (kc + 1 < kend)` between the two chunks the compiler sizes every
     // s_waitcnt of the loop for the path on which the odd chunk's requests were never issued (fewer in flight = less lookahead)
-    if constexpr ((FLAGS & W43_DBG_OLDLOOP) != 0) {
-      for (int kc = kbeg; kc < kend; kc += 2) {
-        chunk(kc, C0{});
-        if (kc + 1 < kend) chunk(kc + 1, C1{});
-      }
-    } else {
-      int kc = kbeg;
-      for (; kc + 1 < kend; kc += 2) {
-        chunk(kc, C0{});
-        chunk(kc + 1, C1{});
-      }
-      if (kc < kend) chunk(kc, C0{});
+    int kc = kbeg;
+    for (; kc + 1 < kend; kc += 2) {
+      chunk(kc, C0{});
+      chunk(kc + 1, C1{});
     }
+    if (kc < kend) chunk(kc, C0{});
   } else {
     for (int kc = kbeg; kc < kend; ++kc) chunk(kc, C0{});
   }
 
   if constexpr (BG && NH == 2) __syncthreads();   // no barrier behind the last dy = 2 stage: the exchange below reuses the activation buffers
-
-  // ---- the next pair of this workgroup (persistent launches): its first loads are in flight during the epilogue ------------
-  constexpr bool PERS = (FLAGS & W43_F_PERSIST) != 0;
-  constexpr int PRE = (FLAGS & W43_F_PRE2) ? 2 : (FLAGS & W43_F_PRE1) ? 1 : 0;
-  static_assert(PERS || PRE == 0, "PRE flags need W43_F_PERSIST");
-  lin += stride;
-  const bool more = PERS && lin < total;
-  if (more) {
-    decode(lin);
-    if constexpr (PRE >= 1) begin_pair_a();
-    if constexpr (PRE >= 2) begin_pair_b();
-  }
 
   // ---- epilogue: y0 = (m0+m1+m2) + (m3+m4), y1 = (m1-m2) + 2(m3-m4) on half 0; y2 = (m1+m2) + 4(m3+m4),
   // y3 = (m1-m2) + (8(m3-m4) + m5) on half 1.  The halves swap the bracketed sums they lack through LDS (the staging
@@ -589,11 +545,6 @@ __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH,
       }
     }
   }
-  if (!more) break;
-  if constexpr (PRE < 1) begin_pair_a();
-  if constexpr (PRE < 2) begin_pair_b();
-  __syncthreads();   // every wave is through with the exchange buffer / the 1x1 tile / its last fragment reads: the staging buffers are free
-  }   // pair loop
 }
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
@@ -614,18 +565,6 @@ hipError_t conv_wino43_launch(const ConvParams& p, hipStream_t s) {
   }
   const int ntx = (p.W + 4 * QW - 1) / (4 * QW), nty = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
-  if (p.persist > 0 && (FLAGS & W43_F_PERSIST) != 0) {   // persistent: `persist` workgroups per CU walk the pairs with stride = the grid size
-    static int ncu[64] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64) dev = 0;
-    if (!ncu[dev]) {
-      hipDeviceProp_t prop;
-      ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    const long long pairs = (long long)grid.x * grid.y, g = (long long)p.persist * ncu[dev];
-    if (g < pairs) grid = dim3((unsigned)g, 1, grid.z);
-  }
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();
 }

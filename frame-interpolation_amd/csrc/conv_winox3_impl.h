@@ -229,7 +229,7 @@ __global__ __launch_bounds__((TH / TM) * (BN / (32 * TN)) * 128) void conv_winox
     const int a_next = a_ad + (a_stage ^ 1) * (A_STAGE / 16);
     auto stage = [&](auto st_c) {
       constexpr int ST = decltype(st_c)::value;
-      // FLAGS 64 / 128 / 256 / 512: timing ablations of tools/conv_bench.hip (no fragment reads / no A item staging /
+      // FLAGS 64 / 128 / 256 / 512: timing ablations of tools/retired/conv_bench.hip (no fragment reads / no A item staging /
       // no weight staging / no barriers) - wrong results, never instantiated by the engine
       if constexpr ((FLAGS & 256) == 0) load_b(s0 + ST + 3, (ST + 1) & 1);
       if constexpr ((FLAGS & 128) == 0) if constexpr ((ST & 1) == 0 && ST / 2 < AH) load_item(ST / 2);

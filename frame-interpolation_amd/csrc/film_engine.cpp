@@ -331,6 +331,14 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
   if ((int64_t)2 * B * H * W >= (int64_t)1 << 31) return fail(h, FILM_ERR_INVALID, "batch too large (2*B*H*W must fit int32)");
   for (auto& p : h->plans)
     if (p->B == B && p->H == H && p->W == W && (!need_device || p->arena)) { *out = p.get(); p->last_use = ++h->tick; return FILM_OK; }
+  if (need_device)   // a description-only plan of this shape (film_plan_json, unit_buffer_bytes) is superseded, not kept beside the new one
+    for (size_t i = 0; i < h->plans.size(); ++i)
+      if (h->plans[i]->B == B && h->plans[i]->H == H && h->plans[i]->W == W) {
+        if (h->last_plan == h->plans[i].get()) h->last_plan = nullptr;
+        free_plan(h->plans[i].get());
+        h->plans.erase(h->plans.begin() + i);
+        break;
+      }
   std::unique_ptr<Plan> P(new Plan);
   int rc = plan_build(h, P.get(), B, H, W);
   if (rc) return rc;

@@ -69,10 +69,6 @@ struct ConvParams {
   const float* pw_bias;
   float* pw_out;
   int pw_ostride, pw_cout;   // pw_cout <= 4
-  // conv_wino43_kernel: > 0 = PERSISTENT launch with this many workgroups per CU (per K split); every workgroup walks the
-  // (patch, channel block) pairs lin, lin + G, ... and requests the first loads of its next pair in front of the epilogue of
-  // the current one.  0: one workgroup per pair.  Same sums either way (bit-identical results).
-  int persist;
 };
 
 // Flow head of a predictor with 32 filters (pyramid_flow_estimator.py:77-83): 1x1 conv Cin -> 16 + leaky_relu,

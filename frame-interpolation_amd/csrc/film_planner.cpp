@@ -133,7 +133,7 @@ struct Planner {
     // Kernel family by layer shape only (never by timing, and not by the batch size): the two kernels sum K in a
     // different order, so the choice must be a pure function of the layer for results to be reproducible across
     // batch sizes and runs.  Halo staging pays where K is deep (traffic bound) or N is too narrow to amortise the
-    // per-tap A gather; measured in tools/conv_bench.hip.
+    // per-tap A gather; measured in tools/retired/conv_bench.hip.
     bool any_up = false;
     for (int i = 0; i < op.nseg; ++i) any_up |= segs[i].up != 0;
     const int64_t px = (int64_t)H * W;
@@ -160,7 +160,7 @@ struct Planner {
       // wino: 1 = fp32 conv_wino_kernel, 2 = conv_winox3_kernel.  The Winograd form wins with the 2 x 2 wave block of
       // its 128-channel tile (0.88-0.94x the time of conv_halo_split_kernel<..,3> per layer, 427 vs 367 TFLOP/s at
       // K = 22 032) and loses with the 64-channel tiles (1.08-1.30x: twice the A staging per MFMA) - per-op profiles of
-      // the two plans and tools/conv_bench.hip agree.
+      // the two plans and tools/retired/conv_bench.hip agree.
       if (L.cout % 128 == 0 || h->opt_wino >= 2) op.split = 0, op.wino = 2;
       else if (op.split == 2) op.wino = 0;
     }

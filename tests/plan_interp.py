@@ -9,6 +9,8 @@ nothing under frame-interpolation_amd/ imports it.
 """
 from __future__ import annotations
 
+import zlib
+
 import numpy as np
 
 from oracle import film_oracle as fo
@@ -31,6 +33,8 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
     arena = np.zeros(plan['arena_floats'], dtype=np.float32)
     bufs = {b['name']: b for b in plan['buffers']}
     B = plan['B']
+    # key of the "weight copies verified" cache: the CONTENT of the blob (an id() can be recycled by a re-packed blob of the same size)
+    blob_key = zlib.crc32(np.ascontiguousarray(packed).view(np.uint8))
     img0 = bufs['img0']
     n = x0.size
     arena[img0['off']:img0['off'] + n] = x0.ravel()
@@ -98,7 +102,7 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             wt = np.ascontiguousarray(wt.transpose(1, 2, 3, 0))
             # the layer's other weight copies are verified once per (layout blob, layer): the shared sub-extractor / flow
             # predictor layers appear in many ops, and several plans are run over one blob
-            vkey = (id(packed), packed.size, op['w_off'], op.get('wh_off', -1), op.get('ww_off', -1), op.get('w2d_off', -1), op.get('ws_off', -1), op.get('wx_off', -1))
+            vkey = (blob_key, packed.size, op['w_off'], op.get('wh_off', -1), op.get('ww_off', -1), op.get('w2d_off', -1), op.get('ws_off', -1), op.get('wx_off', -1))
             check = vkey not in _VERIFIED
             _VERIFIED.add(vkey)
             if check and op.get('wh_off', -1) >= 0:

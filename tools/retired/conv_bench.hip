@@ -1,3 +1,6 @@
+// RETIRED (round 4): the A/B tool of rounds 1-3 (conv_igemm / halo / F(2,3) / F(4,3) variants).  It no longer builds against csrc/: the
+// experiment flags it drove (W43_DBG_*, W43_F_SETPRIO / OLDLOOP / PERSIST / PRE*) and the round-3 nested-Winograd template were removed.
+// tools/w2d_bench.hip is the current tool; the logs this one produced are under profiles/r0[1-3]_*.
 // conv_bench.hip -- micro-benchmark of conv_igemm_kernel variants on the real layer shapes of a 1080p
 // 2x2-tiled forward (4 tiles of 960x576; both images / both directions batched where the engine does).
 // Development tool, not part of the product library.
