@@ -516,13 +516,17 @@ def main():
                 per_kernel[kname]['ms'] += o['ms']
                 per_kernel[kname]['executed_flops'] += f
         exec_tflops = exec_flops / (conv['ms'] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
-        try:  # fabric-side bytes per conv launch REPLAYED from the committed PMC passes of an earlier run (profiles/)
+        traffic, traffic_src, warp_traffic = None, None, None
+        try:  # fabric-side bytes per launch REPLAYED from the committed PMC passes of an earlier run (profiles/)
             import glob
             pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_conv.json')))
             if pmc_files and args.workload == '1080p_2x2':
-                traffic = round(json.load(open(pmc_files[-1]))['hbm_bytes_per_launch'])
+                pmc = json.load(open(pmc_files[-1]))
+                traffic = round(pmc['hbm_bytes_per_launch'])
                 traffic_src = os.path.relpath(pmc_files[-1], ROOT)
+                wcls = next((v for k, v in pmc.get('classes', {}).items() if k.startswith('warp')), None)
+                if wcls and wcls.get('hbm_bytes_per_launch'):
+                    warp_traffic = round(wcls['hbm_bytes_per_launch'])
         except Exception:
             traffic = None
         # the roofline the conv class is priced against: the fp32 MFMA peak in the default mode; in the opt-in
@@ -582,7 +586,10 @@ def main():
             wgbs = cls['warp']['bytes'] / (cls['warp']['ms'] * 1e-3) / 1e9
             extra['roofline_warp'] = {
                 'bound': 'hbm', 'kernel': 'warp_vec_kernel (bilinear gather)', 'achieved': round(wgbs, 1),
-                'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(wgbs / PEAK_HBM_GBS, 4), 'traffic': None,
+                'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(wgbs / PEAK_HBM_GBS, 4),
+                'traffic': warp_traffic if not args.precision else None,
+                'traffic_note': (f'REPLAYED like roofline.traffic ({traffic_src}): (2*FETCH_SIZE + WRITE_SIZE) of the warp launches / their number; '
+                                 f'algorithmic bytes per launch = {cls["warp"]["bytes"] / max(cls["warp"]["launches"], 1):.0f}') if warp_traffic else None,
                 'launches_per_step': cls['warp']['launches'], 'class_ms_per_step': round(cls['warp']['ms'], 3),
                 'algorithmic_bytes_per_step': cls['warp']['bytes'],
             }

@@ -113,7 +113,7 @@ def main():
     else:
         print('\n'.join(lines))
     if args.json and 'conv_mfma' in js:
-        out = {'source': f'{args.md or args.dir} ({args.command}, last forward)', 'kernel': 'conv class: conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf (+ split-K reduce) + first-layer conv_igemm_kernel',
+        out = {'source': f'{args.md or args.dir} ({args.command}, last forward)', 'kernel': 'conv class: conv_wino2d (dominant) / conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf (+ split-K reduce) + first-layer conv_c3 / conv_igemm',
                'fetch_correction': 2.0, 'classes': js, 'hbm_bytes_per_launch': js['conv_mfma'].get('hbm_bytes_per_launch'),
                'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters'}
         json.dump(out, open(args.json, 'w'), indent=1)
