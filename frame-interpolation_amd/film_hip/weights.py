@@ -162,3 +162,26 @@ def load_weights(model_path: str, opt: Options = PUBLISHED) -> Dict[str, np.ndar
         return tf_bundle.load_film_weights(os.path.join(model_path, 'variables', 'variables'), opt)
     raise FileNotFoundError(
         f'{model_path}: neither {WEIGHTS_FILE} nor a SavedModel variables bundle found')
+
+
+def main(argv=None) -> int:
+    """``python -m film_hip.weights <model dir | film_weights.npz> --export blob.bin``: the parameter set as the flat float32
+    blob of ``film_export_packed`` (per layer the HWIO kernel, then the bias) - what a C / C++ host hands to
+    ``film_import_packed``; the SavedModel reader itself stays on the Python side."""
+    import argparse
+    ap = argparse.ArgumentParser(prog='python -m film_hip.weights')
+    ap.add_argument('model_path')
+    ap.add_argument('--export', required=True, help='output file: raw little-endian float32')
+    args = ap.parse_args(argv)
+    from .engine import FilmEngine
+    eng = FilmEngine(PUBLISHED, device=-1)      # plan-only handle: no GPU needed
+    eng.set_weights(load_weights(args.model_path))
+    blob = eng.export_packed()
+    blob.astype('<f4').tofile(args.export)
+    print(f'{args.export}: {blob.size} floats ({blob.nbytes / 1e6:.1f} MB)')
+    eng.close()
+    return 0
+
+
+if __name__ == '__main__':
+    raise SystemExit(main())
