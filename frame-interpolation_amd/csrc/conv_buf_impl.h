@@ -1,6 +1,6 @@
 // conv_buf_impl.h -- implicit-GEMM convolution, register-staged, with the leanest K loop we could build.
 //
-// Same mapping as conv_igemm_impl.h (M = output pixels, N = Cout, K walked in 16-channel steps over
+// Same mapping as tools/retired/conv_igemm_impl.h (M = output pixels, N = Cout, K walked in 16-channel steps over
 // (tap, concat segment, chunk); fp32 v_mfma_f32_32x32x2_f32; bias + leaky_relu epilogue).  Measured on MI355X
 // (tools/retired/conv_bench.hip + rocprofv3 PMC): every non-MFMA vector instruction issued inside the K loop costs
 // matrix-pipe time that the co-resident waves do not win back, while the memory system is nowhere near a limit
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(WGM* WGN * 64) void conv_buf_kernel(ConvParams p) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[kq][nt][j], a[kq][mt][j], acc[mt][nt], 0, 0, 0);   // A = weights: C^T, the same sums
   };
 
-  // ---- two-step prefetch pipeline (see conv_igemm_impl.h for the reasoning behind the shape of this loop) --
+  // ---- two-step prefetch pipeline (see tools/retired/conv_igemm_impl.h for the reasoning behind the shape of this loop) --
   setup_seg();
   setup_tap();
   load_global(sx);  // step 0

@@ -13,7 +13,8 @@
 //     loads are requested before the current tile's MFMAs;
 //   * epilogue: C/D layout col = lane & 31 = output channel, 16 registers = rows m -> one 128-byte row of 32 channels per
 //     register and wave half, straight to the channel slice of the destination.
-// k ascends (tap, channel) in one fma chain per output, like the kernel it replaces.
+// k ascends (tap, channel) in one fma chain per output, like the kernel it replaces.  COUT = the 64 or 32 output channels of a
+// workgroup; blockIdx.z walks the channel blocks of a wider first layer (filters = 96, 128, ...: any multiple of 32).
 #pragma once
 #include "conv_buf_impl.h"
 
@@ -26,21 +27,22 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(ConvParams p) {
   const int ntx = (p.W + 127) >> 7;
   const int tx = (int)blockIdx.x % ntx, ty = (int)blockIdx.x / ntx;
   const int img = blockIdx.y;
+  const int nb0 = (int)blockIdx.z * COUT;   // first output channel of this workgroup
   const int x0 = tx * 128 + wv * 32, yb = ty * ROWS;
   if (x0 >= p.W) return;
 
-  // weights: k = 2 s + half -> (tap, c); row tap * 4 + c of the [48][COUT] first-layer pack; k = 27 is the zero pad
+  // weights: k = 2 s + half -> (tap, c); row tap * 4 + c of the [48][Cout] first-layer pack; k = 27 is the zero pad
   float wb[TN][14];
 #pragma unroll
   for (int s = 0; s < 14; ++s) {
     const int k = 2 * s + half;
     const int tap = k / 3, c = k - tap * 3;
 #pragma unroll
-    for (int nt = 0; nt < TN; ++nt) wb[nt][s] = k < 27 ? p.w[(tap * 4 + c) * COUT + nt * 32 + l31] : 0.f;
+    for (int nt = 0; nt < TN; ++nt) wb[nt][s] = k < 27 ? p.w[(tap * 4 + c) * p.Cout + nb0 + nt * 32 + l31] : 0.f;
   }
   float bias[TN];
 #pragma unroll
-  for (int nt = 0; nt < TN; ++nt) bias[nt] = p.bias[nt * 32 + l31];
+  for (int nt = 0; nt < TN; ++nt) bias[nt] = p.bias[nb0 + nt * 32 + l31];
 
   const ConvSeg& sg = p.seg[0];
   int be = img + sg.boff;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(ConvParams p) {
         const int m = (q & 3) + 8 * (q >> 2) + 4 * half;
         float v = acc[nt][q] + bias[nt];
         if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-        if (x0 + m < p.W) p.out[(rowbase + x0 + m) * p.ostride + nt * 32 + l31] = v;
+        if (x0 + m < p.W) p.out[(rowbase + x0 + m) * p.ostride + nb0 + nt * 32 + l31] = v;
       }
 #pragma unroll
     for (int s = 0; s < 14; ++s) a_cur[s] = a_nxt[s];
@@ -105,8 +107,8 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(ConvParams p) {
 template <int COUT>
 hipError_t conv_c3_launch(const ConvParams& p, hipStream_t s) {
   constexpr int ROWS = 8;
-  if (p.nseg != 1 || p.ksize != 3 || p.Cout != COUT || p.seg[0].C != 3 || p.ksplit > 1) return hipErrorInvalidValue;
+  if (p.nseg != 1 || p.ksize != 3 || p.Cout % COUT || p.seg[0].C != 3 || p.ksplit > 1) return hipErrorInvalidValue;
   const int ntx = (p.W + 127) / 128, nty = (p.H + ROWS - 1) / ROWS;
-  hipLaunchKernelGGL((conv_c3_kernel<COUT, ROWS>), dim3((unsigned)(ntx * nty), (unsigned)p.NB), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((conv_c3_kernel<COUT, ROWS>), dim3((unsigned)(ntx * nty), (unsigned)p.NB, (unsigned)(p.Cout / COUT)), dim3(256), 0, s, p);
   return hipGetLastError();
 }

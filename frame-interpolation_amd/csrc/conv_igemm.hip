@@ -20,9 +20,9 @@
 //   conv_buf_impl.h    the general kernel (1x1, small levels, and the sub-pixel-folded upsample + 2x2 convs): buffer
 //                      loads with hardware zero fill, K-major weights, no vector instruction per K-step besides loads,
 //                      LDS traffic and MFMAs.
-//   conv_igemm_impl.h  the first-generation kernel (64-bit pointers, select-based zero fill, [K][N] weights);
-//                      still runs the 3-channel first layer (its 4-taps-per-step mode) and is the A/B baseline
-//                      of tools/retired/conv_bench.hip.
+//   conv_c3_impl.h     the 3-channel first layer (K = 27): no LDS, weights in registers.
+// (conv_igemm_impl.h, the first-generation kernel that ran the first layer of configurations with filters other than 32 / 64 until
+// round 4, is under tools/retired/.)
 #include "conv_buf_impl.h"
 #include "conv_halo_impl.h"
 #include "conv_split_impl.h"
@@ -31,7 +31,6 @@
 #include "conv_wino2d_impl.h"
 #include "conv_winox3_impl.h"
 #include "conv_foldx3_impl.h"
-#include "conv_igemm_impl.h"
 #include "conv_c3_impl.h"
 
 template <int F>
@@ -48,17 +47,10 @@ static hipError_t launch_shape(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
-// first layer (3-channel image): only the tiles a Cout of 64 / 32 uses
-template <int F>
+// first layer (3-channel image): conv_c3_kernel, 64 output channels per workgroup (32 when Cout is not a multiple of 64)
 static hipError_t launch_c3(const ConvParams& p, int shape, hipStream_t s) {
-  switch (shape) {
-    case TILE_256x64: return conv_igemm_launch<256, 64, 4, 1, 16, F | CONV_F_C3>(p, s);
-    case TILE_128x64: return conv_igemm_launch<128, 64, 2, 2, 16, F | CONV_F_C3>(p, s);
-    case TILE_256x32: return conv_igemm_launch<256, 32, 4, 1, 16, F | CONV_F_C3>(p, s);
-    case TILE_128x32: return conv_igemm_launch<128, 32, 4, 1, 16, F | CONV_F_C3>(p, s);
-    case TILE_C3_DIRECT: return p.Cout == 64 ? conv_c3_launch<64>(p, s) : p.Cout == 32 ? conv_c3_launch<32>(p, s) : hipErrorInvalidValue;
-    default: return hipErrorInvalidValue;
-  }
+  if (shape != TILE_C3_DIRECT) return hipErrorInvalidValue;
+  return p.Cout % 64 == 0 ? conv_c3_launch<64>(p, s) : conv_c3_launch<32>(p, s);
 }
 
 template <int F>
@@ -156,7 +148,6 @@ static hipError_t launch_foldx3(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
-static_assert(CONV_F_XCD_M == CONV_B_XCD_M, "one flag value for both templates");
 
 // Second half of a split-K convolution (film_kernels.h, ConvParams::ksplit): out = act(bias + part[0] + part[1] + ...),
 // partials added in split order.  Thread = one float4 of an output pixel.
@@ -211,8 +202,7 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
     if (p.ksize != 3) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_halo<CONV_B_XCD_M>(p, shape, s) : launch_halo<0>(p, shape, s);
   }
-  if (tile & CONV_TILE_C3)
-    return (tile & CONV_TILE_XCD) ? launch_c3<CONV_F_XCD_M>(p, shape, s) : launch_c3<0>(p, shape, s);
+  if (tile & CONV_TILE_C3) return launch_c3(p, shape, s);
   return (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
 }
 

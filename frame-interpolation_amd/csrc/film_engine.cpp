@@ -216,16 +216,9 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
   std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, op.pw_out.buf >= 0) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
-  if (op.c3) {
-    // conv_c3_kernel and the 3-channel mode of conv_igemm_kernel pair the K = 27 products differently (different
-    // rounding): one family per layer shape, never a timing decision - the direct kernel wherever it exists
+  if (op.c3) {   // the 3-channel first layer has one kernel (conv_c3_kernel)
     cands.clear();
-    if (op.Cout == 64 || op.Cout == 32) cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
-    else
-      for (int sh : (op.Cout % 64 == 0 ? std::vector<int>{TILE_256x64, TILE_128x64} : std::vector<int>{TILE_256x32, TILE_128x32})) {
-        cands.push_back(sh | CONV_TILE_C3);
-        cands.push_back(sh | CONV_TILE_C3 | CONV_TILE_XCD);
-      }
+    cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
   }
   return cands;
 }

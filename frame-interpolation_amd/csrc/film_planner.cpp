@@ -343,7 +343,7 @@ struct Planner {
           op.ksize = 3; op.leaky = 1; op.Cout = k; op.Ctot = 3;
           op.w_off = Lp.w_off; op.b_off = Lp.b_off;
           op.out = tmp; op.NB = N2; op.H = HL(lv); op.W = WL(lv);
-          op.tile = ((k == 64 || k == 32) ? TILE_C3_DIRECT : k % 64 == 0 ? TILE_256x64 : TILE_256x32) | CONV_TILE_XCD | CONV_TILE_C3;
+          op.tile = TILE_C3_DIRECT | CONV_TILE_XCD | CONV_TILE_C3;
           op.flops = 2.0 * N2 * HL(lv) * WL(lv) * k * 27; op.bytes = 4.0 * N2 * HL(lv) * WL(lv) * (3 + k);
           P->ops.push_back(op);
         } else {

@@ -71,6 +71,24 @@ def test_tiny_config_stages(tiny_weights, b, h, w):
     eng.close()
 
 
+@pytest.mark.parametrize('filters', [96, 128])
+def test_first_layer_of_wider_configs(filters):
+    """`filters` other than 32 / 64: the 3-channel first layer runs conv_c3_kernel over several channel blocks (96 = three
+    32-channel workgroups, 128 = two 64-channel ones; until round 4 the first-generation implicit-GEMM kernel did these) and
+    every later layer sees 96 / 192 / 384-channel cascades; per-stage parity against the oracle."""
+    import dataclasses
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    opt = dataclasses.replace(TINY, filters=filters)
+    opt.validate()
+    w = W.make_synthetic_weights(opt, seed=filters)
+    eng = _engine(opt, w)
+    assert all(op['tile'] & 15 == 7 for op in eng.plan(1, 64, 96)['ops'] if op.get('c3'))
+    x0, x1 = _pair(1, 64, 96, seed=filters)
+    _check_stages(eng, opt, w, x0, x1)
+    eng.close()
+
+
 @pytest.fixture(scope='module')
 def published():
     from film_hip import weights as W
