@@ -290,6 +290,15 @@ int autotune_plan(film_t* h, Plan* P) {
           }
       for (size_t c = 0; c < std::max<size_t>(nfin, 1) && c < timed.size(); ++c)
         if (timed[c].first < best_ms) { best_ms = timed[c].first; best = timed[c].second; }
+      // conv_wino2d_kernel: a 64-channel tile within 2 % of the fastest wins - it reads its input patch half as often (45.2 -> 40.2
+      // GB of fabric reads per 1080p forward with the tile forced, same step time: profiles/r04_w2d_tile64_ab.log)
+      if (op.wino == 4 && (best & 15) != W2D_8x64) {
+        float ms64 = 1e30f;
+        int t64 = -1;
+        for (size_t c = 0; c < std::max<size_t>(nfin, 1) && c < timed.size(); ++c)
+          if ((timed[c].second & 15) == W2D_8x64 && timed[c].first < ms64) { ms64 = timed[c].first; t64 = timed[c].second; }
+        if (t64 >= 0 && ms64 <= best_ms * 1.02f) best = t64;
+      }
       h->tune_cache[sig] = best;
     }
     (void)hipEventDestroy(e0);
