@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), 'csrc')
 OUT = os.path.join(_HERE, 'libfilm_hip.so')
 SOURCES = ['conv_igemm.hip', 'misc_kernels.hip', 'film_engine.cpp', 'film_planner.cpp', 'film_layers.cpp']
-HEADERS = ['film_kernels.h', 'film_internal.h', 'conv_igemm_impl.h', 'conv_buf_impl.h', 'conv_halo_impl.h', 'conv_split_impl.h', 'conv_wino_impl.h', 'conv_wino43_impl.h', 'conv_wino2d_impl.h', 'conv_winox3_impl.h', 'conv_foldx3_impl.h', 'conv_c3_impl.h', os.path.join('..', '..', 'include', 'film_hip.h')]
+HEADERS = ['film_kernels.h', 'film_internal.h', 'conv_buf_impl.h', 'conv_halo_impl.h', 'conv_split_impl.h', 'conv_wino_impl.h', 'conv_wino43_impl.h', 'conv_wino2d_impl.h', 'conv_winox3_impl.h', 'conv_foldx3_impl.h', 'conv_c3_impl.h', os.path.join('..', '..', 'include', 'film_hip.h')]
 FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-ffp-contract=off', '-Wno-unused-result']
 
 
