@@ -263,24 +263,26 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------------------
+  // Order of the prologue's requests.  Stage 0 and the first weight slab go out FIRST and alone; everything else - the second slab,
+  // super-chunks 1 and 2: 18 of a wave's 27 requests, ~100 cycles of the CU's address unit each - only behind the barrier that says
+  // stage 0 has landed.  Issued up front (rounds 3-4a) they queued in front of the slower waves' stage-0 requests: the barrier came
+  // 5 800 cycles after wave 0's own share had landed, now 2 900 (profiles/r04_w2d_prologue_order.log: -2 .. -10 % per layer, most on
+  // the short-K layers; super-chunk 1 now lands during chunk 0's MFMAs instead of during the wait).
   raw_setup_seg();
   raw_issue(0);
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmA = __builtin_readcyclecounter();
 #pragma unroll
-  for (int set = 0; set < 2; ++set)
-#pragma unroll
-    for (int j = 0; j < 6; ++j) fbg[set][j] = conv_buf_load(brsrc, bvoff, slab(set) + (unsigned)j * 1024u);
+  for (int j = 0; j < 6; ++j) fbg[0][j] = conv_buf_load(brsrc, bvoff, slab(0) + (unsigned)j * 1024u);
   __builtin_amdgcn_sched_barrier(0);
-  // super-chunks 1 and 2 go out before anybody waits (their latency runs beside stage 0's); this wave's share of stage 0 is older
-  // than the twelve weight requests and these
-  if (nsc > 1) raw_issue(1);
-  if (nsc > 2) raw_issue(2);
-  if (nsc > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + 2 * IPW) : "memory");
-  else if (nsc > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 + IPW) : "memory");
-  else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's share of stage 0 (older than the six weight requests)
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmB = __builtin_readcyclecounter();
   __syncthreads();
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmC = __builtin_readcyclecounter();
+#pragma unroll
+  for (int j = 0; j < 6; ++j) fbg[1][j] = conv_buf_load(brsrc, bvoff, slab(1) + (unsigned)j * 1024u);
+  __builtin_amdgcn_sched_barrier(0);
+  if (nsc > 1) raw_issue(1);
+  if (nsc > 2) raw_issue(2);
   prepare(A[0], 0, C0{});
 
   // ---- K loop: chunk kc = (super-chunk s, half h).  Super-chunk s lives in stage s % 3; chunk kc prepares the fragments of chunk
