@@ -100,10 +100,11 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
       p.flow = op.in2.buf >= 0 ? cptr(arena, op.in2) : nullptr; p.fscale = op.fscale;
       p.dst = mptr(arena, op.out); p.dstride = op.out.stride;
       p.NB = op.NB; p.H = op.H; p.W = op.W;
+      p.src_brot = op.src_brot; p.flow_brot = op.flow_brot; p.misc_nb = op.misc_nb;
       if (op.in3.buf >= 0) { p.coarse = cptr(arena, op.in3); p.flow_out = mptr(arena, op.out2); }
       if (op.img_out.buf >= 0) {   // misc16: both images (img_in = [2 NB] images), both flows
         p.src3 = cptr(arena, op.img_in); p.s3stride = op.img_in.stride;
-        p.src3b = p.src3 + (int64_t)op.NB * op.H * op.W * op.img_in.stride;
+        p.src3b = p.src3 + (int64_t)(op.misc_nb > 0 ? op.misc_nb : op.NB) * op.H * op.W * op.img_in.stride;
         p.dst3 = mptr(arena, op.img_out); p.d3stride = op.img_out.stride;
         p.pack_b = cptr(arena, op.pack_b); p.pack_f = cptr(arena, op.pack_f);
       }

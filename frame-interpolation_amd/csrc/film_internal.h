@@ -97,6 +97,7 @@ struct OpDesc {
   View in3, out2;   // warp: coarser flow to upsample / the upsampled flow it stores; flow heads: in2 = upsampled flow, out2 = v = out + in2
   int NB = 0, H = 0, W = 0;  // conv/warp: output dims; pool: input dims; flow_up: input dims
   float fscale = 1.f;
+  int src_brot = 0, flow_brot = 0, misc_nb = 0;   // warp: one launch for both directions / images of a level (WarpParams)
   int64_t n = 0;
   double flops = 0;  // algorithmic FLOPs (reference channel counts)
   double bytes = 0;  // algorithmic bytes (read once + write once)

@@ -157,6 +157,10 @@ struct WarpParams {
   int d3stride;
   const float* pack_b;
   const float* pack_f;
+  // One launch for both flow directions / both images of a level (batch n = 0 .. NB - 1 of dst and flow_out): the source image of
+  // batch n is (n + src_brot) % NB, its flow (n + flow_brot) % NB (`flow`, not `coarse`); the miscellaneous channels exist for the
+  // first misc_nb batches only (0: for all NB).
+  int src_brot = 0, flow_brot = 0, misc_nb = 0;
 };
 
 // Writes channels [6..15] of the 16-wide "misc" group of an aligned-pyramid level:

@@ -399,18 +399,19 @@ struct Planner {
           up.bytes = 4.0 * N2 * Hl * Wl * 2 * 1.25;
           P->ops.push_back(up);
         }
-        for (int d = 0; d < 2; ++d) {  // warp the OTHER image's features with this direction's flow
-          warp(tg + ":warp_d" + std::to_string(d), view(feat[l], (1 - d) * B, 0, fc[l]), view(vup[l], d * B, 0, 2),
-               view(warped[l], d * B, 0, fc[l]), B, Hl, Wl, 1.f);
-          if (fuse_up) {
-            // tf.image.resize(2 * v) (pyramid_flow_estimator.py:155) inside the warp: the flow of this level is computed
-            // from the coarser level's v by every thread of a pixel and stored once (to vup, which v = res + up reads)
-            OpDesc& w = P->ops.back();
-            w.tag += "+resize2x";
-            w.in2 = View();
-            w.in3 = view(v[l + 1], d * B, 0, 2);
-            w.out2 = view(vup[l], d * B, 0, 2);
-          }
+        // Both directions in ONE launch (batch n = d * B + b, like every other op of the estimator): direction d warps the OTHER
+        // image's features, i.e. the source batch is rotated by B (pyramid_flow_estimator.py:150-158 runs the two directions as
+        // two calls; the arithmetic per pixel is the same).
+        warp(tg + ":warp_d01", view(feat[l], 0, 0, fc[l]), view(vup[l], 0, 0, 2), view(warped[l], 0, 0, fc[l]), N2, Hl, Wl, 1.f);
+        P->ops.back().src_brot = B;
+        if (fuse_up) {
+          // tf.image.resize(2 * v) (pyramid_flow_estimator.py:155) inside the warp: the flow of this level is computed
+          // from the coarser level's v by every thread of a pixel and stored once (to vup, which v = res + up reads)
+          OpDesc& w = P->ops.back();
+          w.tag += "+resize2x";
+          w.in2 = View();
+          w.in3 = view(v[l + 1], 0, 0, 2);
+          w.out2 = view(vup[l], 0, 0, 2);
         }
         sb.v = view(warped[l], 0, 0, fc[l]);
       }
@@ -468,10 +469,18 @@ struct Planner {
     auto emit_align = [&](int l) {
       const size_t first_align_op = P->ops.size();
       const std::string tg = "align_l" + std::to_string(l);
+      // Planar level: the planes of image 0 and image 1 follow each other, i.e. they are ONE [2B][H][W][C] array - both feature warps
+      // in one launch (batch n = s * B + b; image s is sampled with the flow of the opposite direction: the flow batch is rotated by B).
+      const bool pair = P->bufs[aligned[l]].planar > 0;
+      if (pair) {
+        warp(tg + ":warp_feat01", view(feat[l], 0, 0, fc[l]), view(v[l], 0, 0, 2), aligned_part(aligned[l], 0, fc[l]), N2, HL(l), WL(l), 0.5f);
+        P->ops.back().flow_brot = B;
+      }
       for (int s = 0; s < 2; ++s) {
         View fl = view(v[l], (1 - s) * B, 0, 2);
-        warp(tg + ":warp_feat" + std::to_string(s), view(feat[l], s * B, 0, fc[l]), fl,
-             aligned_part(aligned[l], s, fc[l]), B, HL(l), WL(l), 0.5f);
+        if (!pair)
+          warp(tg + ":warp_feat" + std::to_string(s), view(feat[l], s * B, 0, fc[l]), fl,
+               aligned_part(aligned[l], s, fc[l]), B, HL(l), WL(l), 0.5f);
         if (!(h->opt_fuse & 4))
           warp(tg + ":warp_img" + std::to_string(s), view(img[l], s * B, 0, 3), fl,
                sub(aligned_part(aligned[l], 2, fc[l]), 3 * s, 3), B, HL(l), WL(l), 0.5f, false);
@@ -481,6 +490,7 @@ struct Planner {
         // feature warp of the level as one more channel slice (one full 64-byte line per pixel and store)
         OpDesc& w = P->ops.back();
         w.tag += "+misc16";
+        if (pair) w.misc_nb = B;
         w.img_in = view(img[l], 0, 0, 3);             // [2B]: image 0, image 1
         w.img_out = aligned_part(aligned[l], 2, fc[l]);
         w.pack_b = view(v[l], B, 0, 2);   // backward flow (d = 1): samples image 0
@@ -672,7 +682,7 @@ std::string plan_json(film_t* h, const Plan& P) {
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["
       << [&] { std::string d; for (size_t q = 0; q < op.xdeps.size(); ++q) d += (q ? "," : "") + std::to_string(op.xdeps[q]); return d; }() << "]" << ",\"w2_off\":" << op.w2_off << ",\"b2_off\":" << op.b2_off << ",\"c3\":" << op.c3
-      << ",\"fscale\":" << op.fscale << ",\"n\":" << op.n << ",\"flops\":" << op.flops
+      << ",\"fscale\":" << op.fscale << ",\"src_brot\":" << op.src_brot << ",\"flow_brot\":" << op.flow_brot << ",\"misc_nb\":" << op.misc_nb << ",\"n\":" << op.n << ",\"flops\":" << op.flops
       << ",\"bytes\":" << op.bytes << ",";
     json_view(o, "in", op.in, P); o << ",";
     json_view(o, "in2", op.in2, P); o << ",";

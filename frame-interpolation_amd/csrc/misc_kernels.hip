@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int64_t b = blockIdx.z;
   if (blockIdx.x >= nfeat_blocks) {
     __shared__ float4 stage[256 * 4 + 64];   // [pixel][quarter], one float4 of padding per 16 pixels
+    if (p.misc_nb > 0 && b >= p.misc_nb) return;   // (a pair launch: the second half of the batches has no miscellaneous channels)
     const unsigned u0 = (blockIdx.x - nfeat_blocks) * 256u;
     const unsigned u = u0 + threadIdx.x;
     const unsigned band = (unsigned)(p.W * WARP_ROWS);
@@ -334,10 +335,13 @@ __global__ __launch_bounds__(256) void warp_vec_kernel(WarpParams p) {
   const int x = (int)(xt * WARP_TX + (threadIdx.x >> 4)), g = (int)(sl * 16 + (threadIdx.x & 15));
   if (x >= p.W || g >= G) return;
   const int64_t rowpitch = (int64_t)p.W * p.sstride;
-  const float* const img = p.src + b * p.H * rowpitch + g * 4;
+  int bsrc = (int)b + p.src_brot, bflw = (int)b + p.flow_brot;
+  if (bsrc >= p.NB) bsrc -= p.NB;
+  if (bflw >= p.NB) bflw -= p.NB;
+  const float* const img = p.src + (int64_t)bsrc * p.H * rowpitch + g * 4;
   float2 flw[WARP_ROWS];
 #pragma unroll
-  for (int k = 0; k < WARP_ROWS; ++k) flw[k] = warp_flow_at(p, b, min(yb + k, p.H - 1), x);
+  for (int k = 0; k < WARP_ROWS; ++k) flw[k] = warp_flow_at(p, p.coarse ? b : (int64_t)bflw, min(yb + k, p.H - 1), x);
   float4 cbl = float4{0.f, 0.f, 0.f, 0.f}, cbr = cbl;   // bottom corners of the previous row of the band
   int cpix = -(1 << 30);
 #pragma unroll
@@ -502,10 +506,11 @@ hipError_t film_launch_warp(const WarpParams& p, hipStream_t s) {
   if (units >= (1 << 24) || p.H > 65535 || p.NB > 65535) return hipErrorInvalidValue;
   if (p.coarse != nullptr && ((p.H | p.W) & 1)) return hipErrorInvalidValue;
   if (p.C == 3) {
-    if (p.flow_out != nullptr || p.dst3 != nullptr) return hipErrorInvalidValue;
+    if (p.flow_out != nullptr || p.dst3 != nullptr || p.src_brot || p.flow_brot) return hipErrorInvalidValue;
     hipLaunchKernelGGL(warp_c3_kernel, dim3((unsigned)((units + 255) / 256), (unsigned)p.H, (unsigned)p.NB), dim3(256), 0, s, p);
   } else {
     if (p.dst3 != nullptr && (!p.src3 || !p.src3b || !p.pack_b || !p.pack_f)) return hipErrorInvalidValue;
+    if (p.src_brot < 0 || p.src_brot >= p.NB || p.flow_brot < 0 || p.flow_brot >= p.NB || (p.coarse != nullptr && p.flow_brot)) return hipErrorInvalidValue;
     if (p.dst3 != nullptr && ((p.d3stride & 3) || (reinterpret_cast<uintptr_t>(p.dst3) & 15))) return hipErrorInvalidValue;
     const int64_t blocks = (int64_t)((p.W + WARP_TX - 1) / WARP_TX) * ((p.C / 4 + 15) / 16) + (p.dst3 != nullptr ? ((int64_t)p.W * WARP_ROWS + 255) / 256 : 0);
     hipLaunchKernelGGL(warp_vec_kernel, dim3((unsigned)blocks, (unsigned)((p.H + WARP_ROWS - 1) / WARP_ROWS), (unsigned)p.NB), dim3(256), 0, s, p);

@@ -204,23 +204,26 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             b = _view(arena, op['in2'], 1, 1, m)
             _view(arena, op['out'], 1, 1, m)[...] = a + b
         elif k == 'warp':
-            src = np.ascontiguousarray(_view(arena, op['in'], nb, h, w))
+            # one launch may carry both directions / both images of a level: the source (flow) batch of output batch n is
+            # (n + src_brot) % nb ((n + flow_brot) % nb)
+            src = np.roll(np.ascontiguousarray(_view(arena, op['in'], nb, h, w)), -op.get('src_brot', 0), axis=0)
             if op.get('in3', {}).get('buf'):        # fused tf.image.resize(2 * v) of the coarser level, stored to out2
-                assert not op['in2']['buf'] and op['out2']['buf']
+                assert not op['in2']['buf'] and op['out2']['buf'] and not op.get('flow_brot', 0)
                 coarse = np.ascontiguousarray(_view(arena, op['in3'], nb, h // 2, w // 2))
                 flow = fo.resize_bilinear(np.float32(2) * coarse, (h, w))
                 _view(arena, op['out2'], nb, h, w)[...] = flow
             else:
-                flow = np.ascontiguousarray(_view(arena, op['in2'], nb, h, w))
+                flow = np.roll(np.ascontiguousarray(_view(arena, op['in2'], nb, h, w)), -op.get('flow_brot', 0), axis=0)
             _view(arena, op['out'], nb, h, w)[...] = fo.warp(src, np.float32(op['fscale']) * flow)
             if op.get('img_out', {}).get('buf'):    # fused sixteen miscellaneous channels of the aligned level
-                ims = np.ascontiguousarray(_view(arena, op['img_in'], 2 * nb, h, w))
-                bf = np.ascontiguousarray(_view(arena, op['pack_b'], nb, h, w))
-                ff = np.ascontiguousarray(_view(arena, op['pack_f'], nb, h, w))
-                out = _view(arena, op['img_out'], nb, h, w)
+                mb = op.get('misc_nb', 0) or nb
+                ims = np.ascontiguousarray(_view(arena, op['img_in'], 2 * mb, h, w))
+                bf = np.ascontiguousarray(_view(arena, op['pack_b'], mb, h, w))
+                ff = np.ascontiguousarray(_view(arena, op['pack_f'], mb, h, w))
+                out = _view(arena, op['img_out'], mb, h, w)
                 assert op['img_out']['C'] == 16 and op['fscale'] == 0.5
-                out[..., 0:3] = fo.warp(ims[:nb], np.float32(0.5) * bf)    # image 0 <- backward flow
-                out[..., 3:6] = fo.warp(ims[nb:], np.float32(0.5) * ff)    # image 1 <- forward flow
+                out[..., 0:3] = fo.warp(ims[:mb], np.float32(0.5) * bf)    # image 0 <- backward flow
+                out[..., 3:6] = fo.warp(ims[mb:], np.float32(0.5) * ff)    # image 1 <- forward flow
                 out[..., 6:8] = bf * np.float32(0.5)
                 out[..., 8:10] = ff * np.float32(0.5)
                 out[..., 10:16] = 0
