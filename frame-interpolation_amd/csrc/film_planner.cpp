@@ -148,10 +148,13 @@ struct Planner {
     // Winograd F(2,3) along x: where the 1.5x MFMA saving survives its LDS / occupancy cost - wide N, large M.
     // In precision mode bf16x3 the same layers run the Winograd form of the split kernel (conv_winox3_kernel).
     // F(4,3) needs the level width to fill its 64-pixel patches (at most 15 % of the last patch of a row empty)
-    const bool w43_width = L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W);
-    // deep K on a small level (the 36x60 level of a 1080p tile, K = 1920): only with F(4,3) AND its split-K, which cuts the
-    // few long workgroups of such a layer into enough pieces to fill the chip
-    const bool deep_small = L.cout % 128 == 0 && px >= 2048 && px < 8192 && ctot > 1024 && w43_width && h->opt_splitk &&
+    // (levels below 2048 pixels: its Q8 tiles take 32-pixel patches - the 32x32 level of a 256x256 frame)
+    const bool w43_width = L.w43_off >= 0 && (h->opt_wino == 3 || 64 * ((W + 63) / 64) * 100 <= 115 * W ||
+                                              (px < 2048 && 32 * ((W + 31) / 32) * 100 <= 115 * W));
+    // deep K on a small level (the 36x60 level of a 1080p tile, K = 1920; round 4: down to 1024 pixels - the K = 1920 / 2448 layers of
+    // the 32x32 level of a 256x256 frame ran 180-230 us each on the direct kernel, 0.4 of that frame's 2.8 ms): only with F(4,3) AND
+    // its split-K, which cuts the few long workgroups of such a layer into enough pieces to fill the chip
+    const bool deep_small = L.cout % 128 == 0 && px >= 1024 && px < 8192 && ctot > 1024 && w43_width && h->opt_splitk &&
                             h->opt_wino == 1 && h->opt_precision == 0;
     op.wino = op.split != 1 && L.ww_off >= 0 && !any_up && h->opt_wino != 0 &&
               ((L.cout % 128 == 0 && (px >= 8192 || (px >= 2048 && ctot <= 1024))) || (L.cout % 64 == 0 && px >= 30000) ||
