@@ -76,6 +76,40 @@ METRIC = {'4k_4x4_T6': 'interpolated frames/sec @4K (4x4 tiles, times_to_interpo
           '4k_4x4_T2': 'interpolated frames/sec @4K (4x4 tiles, times_to_interpolate 2)'}
 
 
+# Parity of the EXACT timed callable (same DeviceInterpolator, graph, lanes) against the committed reference-graph golden vectors
+# (tests/golden/ref_*.npz: the reference's own create_model / Interpolator code executed by tools/make_ref_golden.py; tf_*.npz from a
+# real TensorFlow install are preferred when present).  workload -> (golden case, batch, H, W, frame_pair kwargs): the inputs the
+# goldens were made with (tests/inputs.py; their checksums are stored in the file and re-checked here).
+PARITY_CASES = {
+    '1080p_2x2': ('1080p', 1, 1080, 1920, dict(seed=2, shift=(11, -17), fg_shift=(-9, 21))),
+    'vimeo_b8': ('vimeo', 8, 256, 448, dict(seed=3)),
+}
+PARITY_TOL = 1e-3   # north_star: |delta| < 1e-3 per pixel, fp32
+
+
+def parity_inputs(workload):
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import golden_util as G
+    import inputs as TI
+    case, b, h, w, kw = PARITY_CASES[workload]
+    g, prov = G.load(case)
+    x0, x1 = TI.frame_pair(b, h, w, **kw)
+    G.check_inputs(g, x0, x1)
+    return g, prov, case, x0, x1
+
+
+def parity_check(workload, fn, dev):
+    """Runs the golden's frame pair through `fn` (the callable the timed loop calls) and returns (output tensor, report dict)."""
+    import golden_util as G
+    g, prov, case, x0, x1 = parity_inputs(workload)
+    got = fn(torch.from_numpy(x0).to(dev), torch.from_numpy(x1).to(dev))
+    torch.cuda.synchronize()
+    d = G.diff(g, 'image', got.cpu().numpy())
+    return got.clone(), {'max_abs_vs_ref_graph_golden' if prov != 'tf' else 'max_abs_vs_tensorflow_golden': d,
+                         'golden': f'tests/golden/{"tf" if prov == "tf" else "ref"}_{case}.npz', 'tolerance': PARITY_TOL,
+                         'through': 'the timed callable itself (DeviceInterpolator, same engine handle / graph / lanes), device-resident frames'}
+
+
 def synth_pair(h, w, seed):
     """smooth random image (uniform noise, 9x9 box filter), second frame = first
     shifted by (3,-2) px + sigma 0.01 noise, so that the flows are non-trivial."""
@@ -189,6 +223,19 @@ def cpu_baseline(weights):
     }
 
 
+def autotune_once(eng, dist, rank, warm, sync=None):
+    """ONE autotune for the job: rank 0 builds + measures its plans with `warm()` while the others wait, then every rank imports
+    rank 0's tile choices (text, film_export_tune) - eight ranks would otherwise each time every candidate, with 8 x 32
+    weight-packing threads on the same host cores, and could end up with different tiles (same results, different speed).
+    `warm` MUST NOT enter a collective: only rank 0 calls it (round-4 ADVICE: the strong-scaling step does, and deadlocked here)."""
+    from film_hip.sharding import share_tune
+    if rank == 0:
+        warm()
+        if sync is not None:
+            sync()
+    share_tune(eng, dist, src=0)
+
+
 def free_port():
     import socket
     with socket.socket() as so:
@@ -231,8 +278,6 @@ def plan_only_run(args, world, rank):
         eng.set_weights(W.make_synthetic_weights(opt, seed=0))
     if world > 1:
         broadcast_weights(eng, dist, src=0)
-        from film_hip.sharding import share_tune
-        share_tune(eng, dist, src=0)       # (plan-only handles measure nothing: the header line travels)
     H, Wd, align, block, tile_hw, ntiles = WORKLOADS[args.workload]
     T = RECURSIONS.get(args.workload, 1)
     b, e = shard_range(args.pairs, world, rank)
@@ -250,6 +295,10 @@ def plan_only_run(args, world, rank):
         drv = TileShardedRecursion(mean, block, dist if world > 1 else None)
         b, e = 0, len(tiles_of_rank(block, world, rank))
     if world > 1:
+        # the same once-per-job autotune sequence as the GPU path below (plan-only handles measure nothing: the header line travels);
+        # in strong mode rank 0 alone warms up - on its own tiles, WITHOUT entering the gather's collectives
+        warm = (lambda: drv.local(f1, f2, T)) if args.scaling == 'strong' else (lambda: eng.plan(max(1, e - b), tile_hw[0], tile_hw[1]))
+        autotune_once(eng, dist, rank, warm)
         dist.barrier()
     t0 = time.perf_counter()
     nops = 0
@@ -267,6 +316,7 @@ def plan_only_run(args, world, rank):
     reported, units = 1, e - b
     digest = float(np.abs(eng.export_packed()[::1013]).sum())
     same = True
+    owned, comm_size = [list(range(b, e))], 1
     if world > 1:
         dist.barrier()
         t = torch.tensor([dt, float(units), 1.0], dtype=torch.float64)
@@ -277,6 +327,9 @@ def plan_only_run(args, world, rank):
         d = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
         dist.all_gather(d, torch.tensor([digest], dtype=torch.float64))
         same = all(float(x) == float(d[0]) for x in d)
+        owned = [None] * world      # which units (tiles when strong, pairs when weak) every rank took
+        dist.all_gather_object(owned, list(drv.tiles) if args.scaling == 'strong' else list(range(*shard_range(args.pairs, world, rank))))
+        comm_size = dist.get_world_size()
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -287,7 +340,8 @@ def plan_only_run(args, world, rank):
                           'config': {'workload': args.workload, 'pairs_sharded': units if args.scaling == 'weak' else None,
                                      'tiles_sharded': units if args.scaling == 'strong' else None,
                                      'stitched_identical_to_one_rank': stitched_ok, 'plan_ops': nops,
-                                     'weights_identical_on_all_ranks': same}}), flush=True)
+                                     'weights_identical_on_all_ranks': same},
+                          'ranks': {'communicator_size': comm_size, 'units_by_rank': owned}}), flush=True)
 
 
 def main():
@@ -421,14 +475,17 @@ def main():
 
     out = None
     if world > 1:
-        # ONE autotune for the job: rank 0 builds + measures its plans with a first step while the others wait, then every rank
-        # imports rank 0's tile choices (text, film_export_tune) - eight ranks would otherwise each time every candidate, with
-        # 8 x 32 weight-packing threads on the same host cores, and could end up with different tiles (same results, different speed)
-        from film_hip.sharding import share_tune
-        if rank == 0:
-            out = step()
-            torch.cuda.synchronize()
-        share_tune(eng, dist, src=0)
+        # strong mode: step() ends in collectives (ok-flag all-reduce + gather), which ranks 1.. would not enter while rank 0
+        # tunes - rank 0 warms up on its own share of the tiles instead (TileShardedRecursion.local: no collective)
+        autotune_once(eng, dist, rank, (lambda: drv.local(x0[0], x1[0], T)) if strong else step, torch.cuda.synchronize)
+    parity, parity_ref = None, None
+    if args.workload in PARITY_CASES and T == 1 and not strong and args.flow_scale == 1.0:
+        parity_ref, parity = parity_check(args.workload, it, dev)
+        if not parity[next(iter(parity))] < PARITY_TOL:
+            sys.stderr.write(f'bench.py: rank {rank}: PARITY FAILED before the timed loop: {json.dumps(parity)}\n')
+            raise SystemExit(3)
+    first = step()
+    first = None if first is None else first.clone()
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
@@ -457,6 +514,21 @@ def main():
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         reported = int(ones.item())
     assert (out is not None or (strong and rank != 0)) and (out is None or bool(torch.isfinite(out).all()))
+    # the timed output itself: the last timed step must reproduce the first call on the same inputs bit for bit (no atomics,
+    # fixed summation orders: a replayed graph that read stale data would show here), and the golden pair pushed through the
+    # timed callable AFTER the loop must reproduce its pre-loop result bit for bit
+    timed_same = None if (out is None or first is None) else bool(torch.equal(out, first))
+    if parity is not None:
+        again, _ = parity_check(args.workload, it, dev)
+        parity['bit_identical_before_and_after_the_timed_loop'] = bool(torch.equal(again, parity_ref))
+        del again, parity_ref
+        if not parity['bit_identical_before_and_after_the_timed_loop']:
+            sys.stderr.write(f'bench.py: rank {rank}: the golden pair changed its result across the timed loop\n')
+            raise SystemExit(3)
+    if timed_same is False:
+        sys.stderr.write(f'bench.py: rank {rank}: the last timed step differs from the first call on the same inputs\n')
+        raise SystemExit(3)
+    del first
 
     result = None
     if rank == 0:
@@ -516,19 +588,24 @@ def main():
                 per_kernel[kname]['ms'] += o['ms']
                 per_kernel[kname]['executed_flops'] += f
         exec_tflops = exec_flops / (conv['ms'] * 1e-3) / 1e12
-        traffic, traffic_src, warp_traffic = None, None, None
-        try:  # fabric-side bytes per launch REPLAYED from the committed PMC passes of an earlier run (profiles/)
+        traffic, traffic_src, warp_traffic, traffic_why = None, None, None, None
+        try:  # fabric-side bytes per launch REPLAYED from the committed PMC passes (profiles/; PMC needs its own rocprofv3
+            # processes) - only from a file made with THIS build of the kernels (film_version() carries a hash of csrc/ + the header)
             import glob
             pmc_files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_conv.json')))
             if pmc_files and args.workload == '1080p_2x2':
                 pmc = json.load(open(pmc_files[-1]))
-                traffic = round(pmc['hbm_bytes_per_launch'])
                 traffic_src = os.path.relpath(pmc_files[-1], ROOT)
-                wcls = next((v for k, v in pmc.get('classes', {}).items() if k.startswith('warp')), None)
-                if wcls and wcls.get('hbm_bytes_per_launch'):
-                    warp_traffic = round(wcls['hbm_bytes_per_launch'])
-        except Exception:
-            traffic = None
+                if pmc.get('build') != eng.version():
+                    traffic_why = (f'{traffic_src} was collected with build "{pmc.get("build")}", this run is "{eng.version()}": not replayed '
+                                   f'(tools/gpu_pmc.sh + tools/pmc_summary.py refresh it)')
+                else:
+                    traffic = round(pmc['hbm_bytes_per_launch'])
+                    wcls = next((v for k, v in pmc.get('classes', {}).items() if k.startswith('warp')), None)
+                    if wcls and wcls.get('hbm_bytes_per_launch'):
+                        warp_traffic = round(wcls['hbm_bytes_per_launch'])
+        except Exception as e:   # noqa: BLE001
+            traffic, traffic_why = None, repr(e)
         # the roofline the conv class is priced against: the fp32 MFMA peak in the default mode; in the opt-in
         # split modes the dense bf16 MFMA peak divided by the bf16 products one fp32 product costs
         peak = {0: PEAK_FP32_MFMA_TFLOPS, 1: PEAK_BF16_MFMA_TFLOPS / 6, 2: PEAK_BF16_MFMA_TFLOPS / 3}[args.precision]
@@ -547,7 +624,8 @@ def main():
                          '(conv_wino2d_kernel: 1/3 of the direct count) lower it while the step gets faster - see direct_equivalent and kernels[]',
             'traffic': traffic if not args.precision else None,
             'traffic_note': (f'REPLAYED, not measured in this run: bytes per launch, (2*FETCH_SIZE + WRITE_SIZE) of the rocprofv3 PMC passes '
-                             f'committed in {traffic_src} (an earlier run of this kernel set; PMC needs its own rocprofv3 process)') if traffic else None,
+                             f'committed in {traffic_src}, collected with the same build of the kernels ("{eng.version()}"; PMC needs its own '
+                             f'rocprofv3 processes)') if traffic else traffic_why,
             # the two Winograd kernels on their own (executed FLOPs: nested F(4,3)x x F(2,3)y = 1/3, 1-D F(4,3) = 1/2 of the direct
             # count); `dominant_kernel` = the one with the larger share of the step
             'kernels': None if args.precision else [
@@ -607,7 +685,11 @@ def main():
                 t_h.append((time.perf_counter() - th0) * 1e3)
             pin_in, pin_out = torch.empty(x0.shape, dtype=torch.float32, pin_memory=True), torch.empty(x0.shape, dtype=torch.float32, pin_memory=True)
             torch.cuda.synchronize()
-            th0 = time.perf_counter(); x0.copy_(pin_in); x1.copy_(pin_in); torch.cuda.synchronize(); h2d = (time.perf_counter() - th0) * 1e3   # noqa: E702
+            pin_in.copy_(x0.cpu())
+            scratch0, scratch1 = torch.empty_like(x0), torch.empty_like(x1)     # never into x0 / x1: later measurements read them
+            torch.cuda.synchronize()
+            th0 = time.perf_counter(); scratch0.copy_(pin_in); scratch1.copy_(pin_in); torch.cuda.synchronize(); h2d = (time.perf_counter() - th0) * 1e3   # noqa: E702
+            del scratch0, scratch1
             th0 = time.perf_counter(); pin_out.copy_(out if out is not None else x0); torch.cuda.synchronize(); d2h = (time.perf_counter() - th0) * 1e3   # noqa: E702
             hm = float(np.median(t_h))
             extra['host_buffers'] = {'ms_per_step': round(hm, 3), 'frames_per_s': round(frames_per_step / (hm * 1e-3), 4),
@@ -632,6 +714,9 @@ def main():
                                       else f'{world} independent GPU(s), weights RCCL-broadcast once',
                        'roofline_profiled_on': f'one model invocation of {prof["B"]} tile(s) / pair(s) of {prof["W"]}x{prof["H"]}',
                        'graph': not args.no_graph, 'lanes': args.lanes},
+            'parity': parity,
+            'timed_output_bit_identical_to_first_call': timed_same,
+            'build': eng.version(),
             'roofline': roofline,
         }
         result.update(extra)
@@ -643,7 +728,7 @@ def main():
                                'weight_broadcast_ms': None if bcast_ms is None else round(bcast_ms, 2),
                                'gather_ms_per_step': (round(drv.gather_ms / max(1, drv.runs), 3) if strong and hasattr(drv, 'gather_ms') else None),
                                'tune': 'rank 0 measured, every rank imported its choices (film_export_tune / film_import_tune)'}
-        if world == 1 and not args.no_split and T == 1:
+        if world == 1 and not args.no_split and T == 1 and '+extra' in eng.version():   # the opt-in modes exist in FILM_EXTRA_FAMILIES=1 builds only
             # Extra, NOT the headline value: the opt-in precision mode "bf16x6" (exact 3-way bf16 split of every fp32
             # operand, six partial products, fp32 accumulate) on the same workload, with its distance from the
             # default fp32-MFMA result.

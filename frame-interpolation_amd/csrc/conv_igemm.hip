@@ -23,15 +23,20 @@
 //   conv_c3_impl.h     the 3-channel first layer (K = 27): no LDS, weights in registers.
 // (conv_igemm_impl.h, the first-generation kernel that ran the first layer of configurations with filters other than 32 / 64 until
 // round 4, is under tools/retired/.)
+// The default library instantiates only the families a default plan can select: conv_wino2d / conv_wino43 / conv_buf / conv_c3.
+// FILM_EXTRA_FAMILIES=1 at build time (film_hip/build.py, Makefile EXTRA=1) adds the ones behind opt-in options: the bf16 split
+// precision modes (conv_split / conv_winox3 / conv_foldx3) and the F(2,3) / halo fp32 kernels (options winograd = 2, halo_all).
 #include "conv_buf_impl.h"
+#include "conv_wino43_impl.h"
+#include "conv_wino2d_impl.h"
+#include "conv_c3_impl.h"
+#ifdef FILM_EXTRA_FAMILIES
 #include "conv_halo_impl.h"
 #include "conv_split_impl.h"
 #include "conv_wino_impl.h"
-#include "conv_wino43_impl.h"
-#include "conv_wino2d_impl.h"
 #include "conv_winox3_impl.h"
 #include "conv_foldx3_impl.h"
-#include "conv_c3_impl.h"
+#endif
 
 template <int F>
 static hipError_t launch_shape(const ConvParams& p, int shape, hipStream_t s) {
@@ -53,6 +58,7 @@ static hipError_t launch_c3(const ConvParams& p, int shape, hipStream_t s) {
   return p.Cout % 64 == 0 ? conv_c3_launch<64>(p, s) : conv_c3_launch<32>(p, s);
 }
 
+#ifdef FILM_EXTRA_FAMILIES
 template <int F>
 static hipError_t launch_halo(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
@@ -94,6 +100,8 @@ static hipError_t launch_wino(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+#endif   // FILM_EXTRA_FAMILIES
+
 template <int F>
 static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
@@ -127,6 +135,7 @@ static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+#ifdef FILM_EXTRA_FAMILIES
 template <int F>
 static hipError_t launch_winox3(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
@@ -147,6 +156,7 @@ static hipError_t launch_foldx3(const ConvParams& p, int shape, hipStream_t s) {
     default: return hipErrorInvalidValue;
   }
 }
+#endif   // FILM_EXTRA_FAMILIES
 
 
 // Second half of a split-K convolution (film_kernels.h, ConvParams::ksplit): out = act(bias + part[0] + part[1] + ...),
@@ -179,6 +189,19 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
     if (p.ksize != 3) return hipErrorInvalidValue;   // (fused pool / 1x1: checked by the launcher)
     return (tile & CONV_TILE_XCD) ? launch_wino2d<CONV_B_XCD_M>(p, shape, s) : launch_wino2d<0>(p, shape, s);
   }
+#ifndef FILM_EXTRA_FAMILIES
+  // families that are not in this build (the planner never selects them without FILM_EXTRA_FAMILIES)
+  if ((tile & (CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_X3)) || ((tile & CONV_TILE_WINO) && !(tile & CONV_TILE_F43)))
+    return hipErrorNotSupported;
+  if (tile & CONV_TILE_WINO) {
+    if (p.ksize != 3) return hipErrorInvalidValue;
+    if (p.pool_out != nullptr && shape < W43_Q16_4x64_T21) return hipErrorInvalidValue;   // fused pool: 64-pixel tiles only
+    if (p.pw_out != nullptr && ((shape != W43_Q16_4x64_N1 && shape != W43_Q16_4x64_N1_P2 && shape != W43_Q8_8x64_N1_P2) || p.Cout != 64 || p.ksplit > 1 ||
+                                p.pool_out != nullptr || p.pw_cout < 1 || p.pw_cout > 4))
+      return hipErrorInvalidValue;   // fused 1x1: a workgroup must hold all 64 channels of its pixels in one wave set
+    return (tile & CONV_TILE_XCD) ? launch_wino43<CONV_B_XCD_M>(p, shape, s) : launch_wino43<0>(p, shape, s);
+  }
+#else
   if (tile & CONV_TILE_FOLDX3) {
     if (p.ksize != 2 || p.fold != 2) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_foldx3<CONV_B_XCD_M>(p, shape, s) : launch_foldx3<0>(p, shape, s);
@@ -202,6 +225,7 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
     if (p.ksize != 3) return hipErrorInvalidValue;
     return (tile & CONV_TILE_XCD) ? launch_halo<CONV_B_XCD_M>(p, shape, s) : launch_halo<0>(p, shape, s);
   }
+#endif   // FILM_EXTRA_FAMILIES
   if (tile & CONV_TILE_C3) return launch_c3(p, shape, s);
   return (tile & CONV_TILE_XCD) ? launch_shape<CONV_B_XCD_M>(p, shape, s) : launch_shape<0>(p, shape, s);
 }

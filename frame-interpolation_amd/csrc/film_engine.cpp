@@ -425,7 +425,17 @@ int film_to_uint8(const float* src, unsigned char* dst, int64_t n, void* stream)
   return film_launch_to_uint8(src, dst, n, (hipStream_t)stream) == hipSuccess ? FILM_OK : FILM_ERR_HIP;
 }
 
-const char* film_version(void) { return "gfx950;film_hip r4"; }
+#ifndef FILM_SRC_ID
+#define FILM_SRC_ID "unknown"
+#endif
+#ifdef FILM_EXTRA_FAMILIES
+#define FILM_FLAVOUR "+extra"
+#else
+#define FILM_FLAVOUR ""
+#endif
+// "gfx950;film_hip r5;src=<sha1[:12] of csrc/ + include/film_hip.h>[+extra]": ties tune caches, bench lines and PMC summaries to the
+// kernel sources they were produced with (film_hip/build.py source_id(), `make print-src-id`)
+const char* film_version(void) { return "gfx950;film_hip r5;src=" FILM_SRC_ID FILM_FLAVOUR; }
 
 int film_default_config(film_config* cfg) {
   if (!cfg) return FILM_ERR_INVALID;
@@ -531,6 +541,9 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "winograd")) {
     if (value < 0 || value > 3) return fail(h, FILM_ERR_INVALID, "winograd: 0, 1, 2 or 3");
+#ifndef FILM_EXTRA_FAMILIES
+    if (value == 2) return fail(h, FILM_ERR_INVALID, "winograd = 2 (F(2,3) kernel on every level) needs a library built with FILM_EXTRA_FAMILIES=1");
+#endif
     if ((int)value != h->opt_wino) {  // plans carry the kernel choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
@@ -540,6 +553,9 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "halo_all")) {
+#ifndef FILM_EXTRA_FAMILIES
+    if (value) return fail(h, FILM_ERR_INVALID, "halo_all needs a library built with FILM_EXTRA_FAMILIES=1");
+#endif
     if ((value != 0) != (h->opt_halo_all != 0)) {  // plans carry the kernel choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
@@ -600,6 +616,9 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   }
   else if (!strcmp(key, "precision")) {
     if (value != 0 && value != 1 && value != 2) return fail(h, FILM_ERR_INVALID, "precision: 0 (f32), 1 (bf16x6) or 2 (bf16x3)");
+#ifndef FILM_EXTRA_FAMILIES
+    if (value) return fail(h, FILM_ERR_INVALID, "precision %d (bf16 split modes) needs a library built with FILM_EXTRA_FAMILIES=1; this build runs fp32 MFMA only", (int)value);
+#endif
     if ((int)value != h->opt_precision) {  // plans carry the kernel choice: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipStreamSynchronize(h->stream); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());

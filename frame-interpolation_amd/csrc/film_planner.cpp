@@ -129,6 +129,15 @@ struct Planner {
       return;
     }
     op.out = out; op.NB = NB; op.H = H; op.W = W;
+    // every MFMA convolution stores dwordx4 (four channels of a pixel per lane): the destination slice must start on a multiple of
+    // four floats of a pixel whose pitch is one.  film_create only accepts configurations (filters % 32 == 0, flow filters 32 or
+    // % 64) for which every slice does; a layout that breaks this must fail HERE with a message, not as hipErrorInvalidValue at
+    // launch time (round-4 ADVICE)
+    if (out.off % 4 != 0 || out.stride % 4 != 0 || L.cout % 32 != 0) {
+      bad = true;
+      bad_msg = "planner: " + op.tag + " writes " + std::to_string(L.cout) + " channels at float offset " + std::to_string(out.off) + " of a " +
+                std::to_string(out.stride) + "-float pixel: the convolution kernels need Cout % 32 == 0 and 16-byte aligned output slices";
+    }
     const int64_t M = (int64_t)NB * H * W;
     // Kernel family by layer shape only (never by timing, and not by the batch size): the two kernels sum K in a
     // different order, so the choice must be a pure function of the layer for results to be reproducible across
@@ -184,6 +193,12 @@ struct Planner {
         (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= h->opt_w2d_min_px)))
       op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
+#ifndef FILM_EXTRA_FAMILIES
+    // default build: the halo / F(2,3) / bf16 split kernels are not in the library (film_set_option refuses the options that ask for
+    // them); a layer the nested / F(4,3) kernels cannot take runs on the general kernel
+    op.halo = 0; op.split = 0;
+    if (op.wino == 1 || op.wino == 2) op.wino = 0;
+#endif
     need_groups(op.split || op.wino == 2 ? 4 : op.halo ? 3 : op.wino == 1 ? 2 : 1);
     op.tile = op.wino == 4 ? ((L.cout % 64 == 0 ? W2D_8x64 : W2D_8x32) | CONV_TILE_W2D | CONV_TILE_XCD)
               : op.wino == 3 ? ((L.cout % 64 == 0 ? W43_Q16_4x64_T21_P2 : W43_Q16_4x32_T11_BG) | CONV_TILE_WINO | CONV_TILE_F43 | CONV_TILE_XCD)

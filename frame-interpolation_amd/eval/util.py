@@ -95,29 +95,40 @@ def interpolate_pairs_to_files(inputs: List[str], first: int, end: int, n_pairs:
                 kept[index] = pixels
             pending.append(enc.submit(write_image_uint8, f'{frames_dir}/frame_{index:03d}.png', pixels))
 
-        # decode ahead: the two inputs of the first pair at once, then always one file beyond the pair being interpolated
-        reads = {i: enc.submit(read_image, inputs[i]) for i in range(first, min(first + 2, end + 1))} if end > first else {}
-        for p in range(first, end):
-            f1 = reads.pop(p).result() if p in reads else read_image(inputs[p])
-            f2 = reads[p + 1].result()                      # (stays in `reads`: it is the next pair's first frame)
-            if p + 2 <= end:
-                reads[p + 2] = enc.submit(read_image, inputs[p + 2])
-            emit(p * step, to_uint8(f1))
-            written += 1
-            if T > 0:
-                a = torch.from_numpy(np.ascontiguousarray(f1, dtype=np.float32)).to(dev, non_blocking=False)
-                b = torch.from_numpy(np.ascontiguousarray(f2, dtype=np.float32)).to(dev, non_blocking=False)
-                futs = stream.run(a, b, T, lambda k, px, base=p * step: emit(base + k, px))
-                for fu in futs:
-                    fu.result()
-                written += step - 1
-            if p == n_pairs - 1:
-                emit((p + 1) * step, to_uint8(f2))
+        reads = {}
+        try:
+            # decode ahead: the two inputs of the first pair at once, then always one file beyond the pair being interpolated
+            reads = {i: enc.submit(read_image, inputs[i]) for i in range(first, min(first + 2, end + 1))} if end > first else {}
+            for p in range(first, end):
+                f1 = reads.pop(p).result() if p in reads else read_image(inputs[p])
+                f2 = reads[p + 1].result()                      # (stays in `reads`: it is the next pair's first frame)
+                if p + 2 <= end:
+                    reads[p + 2] = enc.submit(read_image, inputs[p + 2])
+                emit(p * step, to_uint8(f1))
                 written += 1
-        for fu in pending:
-            fu.result()
-        stream.close()
-    engine.save_tune_cache()
+                if T > 0:
+                    a = torch.from_numpy(np.ascontiguousarray(f1, dtype=np.float32)).to(dev, non_blocking=False)
+                    b = torch.from_numpy(np.ascontiguousarray(f2, dtype=np.float32)).to(dev, non_blocking=False)
+                    futs = stream.run(a, b, T, lambda k, px, base=p * step: emit(base + k, px))
+                    for fu in futs:
+                        fu.result()
+                    written += step - 1
+                if p == n_pairs - 1:
+                    emit((p + 1) * step, to_uint8(f2))
+                    written += 1
+            for fu in pending:
+                fu.result()
+        except BaseException:
+            # a failed forward / decode / encode: do not let the queued PNG writes run on (a half-written frames directory that
+            # looks finished), do not leak the stream's worker pool (round-4 ADVICE)
+            for fu in pending:
+                fu.cancel()
+            for fu in reads.values():
+                fu.cancel()
+            raise
+        finally:
+            stream.close()
+            engine.save_tune_cache()
     return written, ([kept[i] for i in sorted(kept)] if kept is not None else None)
 
 

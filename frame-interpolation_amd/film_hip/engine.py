@@ -16,7 +16,10 @@ import numpy as np
 from .options import Options, PUBLISHED
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libfilm_hip.so')
+# FILM_HIP_LIB=<path> names the library explicitly; FILM_EXTRA_FAMILIES=1 selects the flavour that also holds the opt-in kernel
+# families (bf16 precision modes, F(2,3) / halo kernels: film_hip/build.py), built next to the default one
+LIB_PATH = os.environ.get('FILM_HIP_LIB') or os.path.join(
+    _HERE, 'libfilm_hip_extra.so' if os.environ.get('FILM_EXTRA_FAMILIES', '0') not in ('', '0') else 'libfilm_hip.so')
 
 FILM_MEM_HOST = 0
 FILM_MEM_DEVICE = 1
@@ -60,14 +63,16 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
         raise FileNotFoundError(
             f'{p} not found: build the HIP engine first (python -c "import __graft_entry__ as g; g.build()" '
             'or make -C frame-interpolation_amd/csrc). There is no CPU fallback.')
-    try:
-        # PyTorch-ROCm bundles its own HIP runtime; importing it first makes libfilm_hip.so (whose
-        # DT_NEEDED is the unversioned "libamdhip64.so", see film_hip/build.py) bind to that same
-        # runtime, so device pointers and streams can be exchanged with torch.  Without torch the
-        # system runtime under /opt/rocm/lib is used.
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover
-        pass
+    if os.environ.get('FILM_NO_TORCH', '0') in ('', '0'):
+        try:
+            # PyTorch-ROCm bundles its own HIP runtime; importing it first makes libfilm_hip.so (whose
+            # DT_NEEDED is the unversioned "libamdhip64.so", see film_hip/build.py) bind to that same
+            # runtime, so device pointers and streams can be exchanged with torch.  Without torch (or with
+            # FILM_NO_TORCH=1: a torch-free host, tools/graph_race_check.py on the system runtime) the
+            # runtime under /opt/rocm/lib is used.
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover
+            pass
     lib = ctypes.CDLL(p)
     vp, cp, i64p, fp = ctypes.c_void_p, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p
     lib.film_default_config.argtypes = [ctypes.POINTER(_Config)]
@@ -103,6 +108,24 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     if path is None:
         _lib = lib
     return lib
+
+
+def hip_runtime_info() -> Tuple[str, int, str]:
+    """(path, hipRuntimeGetVersion(), 'major.minor.patch') of the HIP runtime libfilm_hip.so is bound to in THIS process: PyTorch's
+    bundled libamdhip64.so when torch was imported first, /opt/rocm/lib's otherwise (film_hip/build.py).  HIP_VERSION is
+    major * 10^7 + minor * 10^5 + patch: 70226015 is HIP 7.2.26015, not 7.0.2."""
+    load_library()
+    path = ''
+    with open('/proc/self/maps') as f:
+        for line in f:
+            if 'libamdhip64' in line:
+                path = line.split()[-1]
+                break
+    if not path:
+        return '', 0, 'not loaded'
+    v = ctypes.c_int(0)
+    ctypes.CDLL(path).hipRuntimeGetVersion(ctypes.byref(v))
+    return path, v.value, f'{v.value // 10000000}.{v.value // 100000 % 100}.{v.value % 100000}'
 
 
 def _cfg_struct(opt: Options) -> _Config:
@@ -336,3 +359,8 @@ class FilmEngine:
     @staticmethod
     def version() -> str:
         return load_library().film_version().decode()
+
+    @staticmethod
+    def has_extra_families() -> bool:
+        """True for a FILM_EXTRA_FAMILIES=1 build: the precision modes and the winograd = 2 / halo_all options exist."""
+        return '+extra' in FilmEngine.version()

@@ -158,7 +158,7 @@ class TileShardedRecursion:
         self.tiles = tiles_of_rank(self.block_shape, self.world, self.rank)
         self.counts = [len(tiles_of_rank(self.block_shape, self.world, r)) for r in range(self.world)]
         self._recv, self._recv_key = None, None
-        self.gather_ms, self.runs = 0.0, 0     # time spent in the gather collective / number of run() calls (bench.py reports it)
+        self._gather_ms, self._events, self.runs = 0.0, [], 0     # time spent in the gather collective (property gather_ms) / number of run() calls
 
     def local(self, frame1, frame2, times_to_interpolate: int):
         """This rank's share: [2^T + 1, n_own, ph, pw, 3]."""
@@ -167,7 +167,8 @@ class TileShardedRecursion:
 
     def gather(self, local_mids):
         """[F, n_own, ph, pw, 3] of every rank -> the list of per-rank receive buffers [F, nmax, ph, pw, 3] on rank dst (None
-        elsewhere; one rank: [local_mids]).  One gather of equally sized (padded to the largest share) buffers; rank r's tiles are
+        elsewhere; one rank: [local_mids]).  The buffers are REUSED: they are valid until the next gather() / run() of this object
+        (run() copies the frames out of them before it returns).  One gather of equally sized (padded to the largest share) buffers; rank r's tiles are
         the contiguous range shard_range gives.  Before the gather every rank contributes an "ok" flag to an all-reduce: a rank
         whose recursion failed makes ALL ranks raise instead of leaving the others in the collective until its timeout.  The
         receive buffers are allocated once per shape and reused (round-3 ADVICE); gather_ms / runs time the collective."""
@@ -195,14 +196,29 @@ class TileShardedRecursion:
                 self._recv_key = key
             recv = self._recv
         if send.is_cuda:
-            torch.cuda.synchronize(send.device)
-        t0 = time.perf_counter()
-        self.dist.gather(send, recv, dst=self.dst)
-        if send.is_cuda:
-            torch.cuda.synchronize(send.device)
-        self.gather_ms += (time.perf_counter() - t0) * 1e3
+            # device events on the current stream (the collective is ordered against it): the time of the gather itself, without
+            # draining the compute in front of it into the measurement and without a host synchronisation per run (round-4 ADVICE);
+            # gather_ms is read lazily, see the property
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.dist.gather(send, recv, dst=self.dst)
+            e1.record()
+            self._events.append((e0, e1))
+        else:
+            t0 = time.perf_counter()
+            self.dist.gather(send, recv, dst=self.dst)
+            self._gather_ms += (time.perf_counter() - t0) * 1e3
         self.runs += 1
         return recv if self.rank == self.dst else None
+
+    @property
+    def gather_ms(self) -> float:
+        """Milliseconds spent in the gather collectives so far (synchronises on the recorded events when first read)."""
+        for e0, e1 in self._events:
+            e1.synchronize()
+            self._gather_ms += e0.elapsed_time(e1)
+        self._events = []
+        return self._gather_ms
 
     def _device(self, t):
         import torch

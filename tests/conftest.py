@@ -31,6 +31,21 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
 
 
+def has_extra_families() -> bool:
+    """The loaded libfilm_hip flavour holds the opt-in kernel families (FILM_EXTRA_FAMILIES=1 build: bf16 precision modes,
+    F(2,3) / halo kernels).  The default library - what the driver builds and tests - does not."""
+    from film_hip.engine import FilmEngine
+    try:
+        return FilmEngine.has_extra_families()
+    except Exception:   # library not built: the tests that need it fail on their own
+        return False
+
+
+needs_extra_families = pytest.mark.skipif(
+    "not __import__('conftest').has_extra_families()",
+    reason='needs the FILM_EXTRA_FAMILIES=1 flavour of the library (FILM_EXTRA_FAMILIES=1 python -m film_hip.build; run pytest with FILM_EXTRA_FAMILIES=1)')
+
+
 def oracle_options(opt):
     from oracle import film_oracle as fo
     return fo.Options(pyramid_levels=opt.pyramid_levels, fusion_pyramid_levels=opt.fusion_pyramid_levels,

@@ -219,6 +219,30 @@ def test_bench_strong_scaling_launcher_world2_plan_only():
     assert r['config']['stitched_identical_to_one_rank'] is True and r['config']['weights_identical_on_all_ranks'] is True
 
 
+def test_bench_strong_scaling_world8_4k_t6_plan_only():
+    """First contact with the driver's 8-GPU tier, rehearsed on CPU: `bench.py --gpus 8 --scaling strong --workload 4k_4x4_T6`
+    (BASELINE configs[4]: 16 tiles over 8 ranks, the whole T = 6 tree tile-local, one gather) through the real launcher with gloo
+    and plan-only handles - including the once-per-job autotune sequence in front of the timed loop, in which only rank 0 warms up
+    and must not enter a collective (round-4 ADVICE: it did, and deadlocked).  Eight ranks answer, every tile is owned exactly once
+    by contiguous pairs, the stitched 65-frame sequence equals the one-rank result."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    env.pop('RANK', None)
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--plan-only', '--tiny-net', '--steps', '1',
+                          '--warmup', '0', '--scaling', 'strong', '--workload', '4k_4x4_T6'],
+                         capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    r = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][0])
+    assert r['n_gpus'] == 8 and r['scaling'] == 'strong' and r['config']['tiles_sharded'] == 16
+    assert r['ranks']['communicator_size'] == 8
+    assert r['ranks']['units_by_rank'] == [[2 * g, 2 * g + 1] for g in range(8)]
+    assert r['config']['stitched_identical_to_one_rank'] is True and r['config']['weights_identical_on_all_ranks'] is True
+
+
 def _failing_worker(rank, world, port, q):
     import sys
     for p in (ROOT, PKG):

@@ -158,7 +158,9 @@ def test_second_weight_set_on_a_used_engine(tiny_weights):
     w2 = W.make_synthetic_weights(TINY, seed=11)
     x0, x1 = TI.frame_pair(1, 128, 96, seed=3)
     eng = _engine(TINY, tiny_weights)
-    for key, val in (('winograd', 0), ('winograd', 2), ('winograd', 1)):    # plans on the halo / F(2,3) / default families
+    from conftest import has_extra_families
+    # plans on the halo (general kernel in the default build) / F(2,3) (FILM_EXTRA_FAMILIES builds only) / default families
+    for key, val in (('winograd', 0),) + ((('winograd', 2),) if has_extra_families() else ()) + (('winograd', 1),):
         eng.set_option(key, val)
         first = eng.forward(x0, x1)
         eng.set_weights(w2)

@@ -212,9 +212,15 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
     from film_hip.engine import FilmEngine, FilmError
     from film_hip.options import PUBLISHED
     WINO, SPLIT, X3, FOLDX3, F43, W2D = 256, 128, 512, 1024, 2048, 8192
+    from conftest import has_extra_families
     eng = FilmEngine(PUBLISHED, device=-1)
     fam = {}
-    for mode in (0, 1, 2):
+    modes = (0, 1, 2) if has_extra_families() else (0,)
+    if not has_extra_families():     # the default library holds the fp32 families only and says so
+        for key, val in (('precision', 1), ('precision', 2), ('winograd', 2), ('halo_all', 1)):
+            with pytest.raises(FilmError, match='FILM_EXTRA_FAMILIES'):
+                eng.set_option(key, val)
+    for mode in modes:
         eng.set_option('precision', mode)
         per_batch = []
         for b in (1, 4):
@@ -231,11 +237,14 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
         fam[mode] = per_batch[0]
     assert all(s == 0 and w in (0, 1, 3, 4) for _, s, w, _ in fam[0])
     assert any(w == 4 for _, _, w, _ in fam[0])      # the nested-Winograd family: deep-K layers of the 128x224 level (mode 0 only)
-    assert not any(w == 4 for m in (1, 2) for _, _, w, _ in fam[m])
-    assert any(s == 1 for _, s, _, _ in fam[1]) and all(w == 0 for _, s, w, _ in fam[1] if s)
-    assert any(w == 2 for _, _, w, _ in fam[2]) and any(s == 2 and not f for _, s, _, f in fam[2])
-    assert any(s == 2 and f == 2 for _, s, _, f in fam[2])
-    assert not any(s == 1 or w == 1 and s for _, s, w, _ in fam[2])
+    if has_extra_families():
+        assert not any(w == 4 for m in (1, 2) for _, _, w, _ in fam[m])
+        assert any(s == 1 for _, s, _, _ in fam[1]) and all(w == 0 for _, s, w, _ in fam[1] if s)
+        assert any(w == 2 for _, _, w, _ in fam[2]) and any(s == 2 and not f for _, s, _, f in fam[2])
+        assert any(s == 2 and f == 2 for _, s, _, f in fam[2])
+        assert not any(s == 1 or w == 1 and s for _, s, w, _ in fam[2])
+    else:
+        assert all(w in (0, 3, 4) for _, _, w, _ in fam[0])     # no F(2,3) / halo / split kernel can be selected
     with pytest.raises(FilmError):
         eng.set_option('precision', 3)
 
@@ -443,6 +452,9 @@ def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_w
     eng.set_option('wino2d', 0)                         # (the nested kernel reads group 0: without it the levels of this frame need F(2,3) / halo copies)
     base = eng.export_layouts().size
     kinds = {(op['halo'], op['wino']) for op in eng.plan(1, 128, 96)['ops'] if op['kind'] == 'conv_mfma'}
+    from conftest import has_extra_families
+    if not has_extra_families():                        # default library: no plan selects those families; pull the groups in by option
+        eng.set_option('pack_groups', 3)
     grown = eng.export_layouts().size
     assert grown > base, ('the test needs a plan that reads an on-demand layout group', kinds)
     eng.import_packed(eng.export_packed())              # same weights again: extent and bytes unchanged
@@ -455,6 +467,8 @@ def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_w
     fresh.set_weights(w2)
     fresh.set_option('wino2d', 0)
     fresh.plan(1, 128, 96)
+    if not has_extra_families():
+        fresh.set_option('pack_groups', 3)
     assert np.array_equal(after, fresh.export_layouts())
 
 
