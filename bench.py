@@ -87,8 +87,13 @@ PARITY_CASES = {
 PARITY_TOL = 1e-3   # north_star: |delta| < 1e-3 per pixel, fp32
 
 
+def _tests_on_path():
+    if os.path.join(ROOT, 'tests') not in sys.path:
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+
 def parity_inputs(workload):
-    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    _tests_on_path()
     import golden_util as G
     import inputs as TI
     case, b, h, w, kw = PARITY_CASES[workload]
@@ -100,6 +105,7 @@ def parity_inputs(workload):
 
 def parity_check(workload, fn, dev):
     """Runs the golden's frame pair through `fn` (the callable the timed loop calls) and returns (output tensor, report dict)."""
+    _tests_on_path()
     import golden_util as G
     g, prov, case, x0, x1 = parity_inputs(workload)
     got = fn(torch.from_numpy(x0).to(dev), torch.from_numpy(x1).to(dev))

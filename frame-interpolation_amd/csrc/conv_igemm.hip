@@ -231,8 +231,8 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
 }
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
-  // split-K is implemented by conv_buf_kernel and conv_wino43_kernel only
-  const bool can_split = !(tile & (CONV_TILE_W2D | CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
+  // split-K is implemented by conv_buf_kernel, conv_wino43_kernel and conv_wino2d_kernel
+  const bool can_split = !(tile & (CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
                          (!(tile & CONV_TILE_WINO) || (tile & CONV_TILE_F43));
   if (p.ksplit > 1 && !can_split) return hipErrorInvalidValue;
   const hipError_t e = film_launch_conv_main(p, tile, s);

@@ -156,6 +156,18 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     rc0 += 16;
     if (rc0 >= rsegC && rsg + 1 < p.nseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
   };
+  // split-K (ConvParams::ksplit, film_kernels.h; round 5): blockIdx.z = split z sums the super-chunks [sc0, sc1) of the K loop and
+  // writes RAW partial sums to part[z][pixel][Cout]; conv_splitk_reduce_kernel adds them in split order with the bias and the
+  // activation.  For the deep-K layers of the levels whose workgroup count leaves the chip half empty in its last round (72x120:
+  // 2304 workgroups on 512 slots = 4.5 rounds of 0.5 ms) or does not fill it at all (36x60: 640 workgroups).
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+  const int nsc_all = p.Ctot / 16;
+  const int sc0 = (int)((long long)nsc_all * blockIdx.z / ksp), sc1 = (int)((long long)nsc_all * (blockIdx.z + 1) / ksp);
+  if (ksp > 1) {   // the DMA cursor starts at this split's first super-chunk: walk the concat segments
+    int c = sc0 * 16;
+    while (rsg + 1 < p.nseg && c >= p.seg[rsg].C) { c -= p.seg[rsg].C; ++rsg; }
+    rc0 = c;
+  }
   auto raw_issue = [&](int stage) {
 #pragma unroll
     for (int n = 0; n < IPW; ++n) dma_piece(n, stage);
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   };
 
   // ---- weights: [Cout / 32][chunk][mu][nu][K half][32][4] floats; this wave reads slab (ct, kc, mu): 6 x 1 KB -----------------
-  const int nkc = p.Ctot / 8, nsc = nkc / 2;
+  const int nkc = p.Ctot / 8, nsc = sc1 - sc0, kc0 = 2 * sc0, kc1 = 2 * sc1;
   const conv_rsrc_t brsrc = conv_make_rsrc(uniform_ptr(p.w));
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const int ct = n0 / 32 + ng;
@@ -272,14 +284,14 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   raw_issue(0);
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmA = __builtin_readcyclecounter();
 #pragma unroll
-  for (int j = 0; j < 6; ++j) fbg[0][j] = conv_buf_load(brsrc, bvoff, slab(0) + (unsigned)j * 1024u);
+  for (int j = 0; j < 6; ++j) fbg[0][j] = conv_buf_load(brsrc, bvoff, slab(kc0) + (unsigned)j * 1024u);
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // this wave's share of stage 0 (older than the six weight requests)
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmB = __builtin_readcyclecounter();
   __syncthreads();
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmC = __builtin_readcyclecounter();
 #pragma unroll
-  for (int j = 0; j < 6; ++j) fbg[1][j] = conv_buf_load(brsrc, bvoff, slab(1) + (unsigned)j * 1024u);
+  for (int j = 0; j < 6; ++j) fbg[1][j] = conv_buf_load(brsrc, bvoff, slab(kc0 + 1) + (unsigned)j * 1024u);
   __builtin_amdgcn_sched_barrier(0);
   if (nsc > 1) raw_issue(1);
   if (nsc > 2) raw_issue(2);
@@ -305,11 +317,11 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       // and the 6 weight requests of chunk 0).  Everybody else's are published by the barrier.
       if constexpr ((FLAGS & W2D_DBG_NOB) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else {
-        if (kc == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (kc == kc0 + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       }
       if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
-      dma_on = (kc >> 1) + NS < nsc;
+      dma_on = (kc >> 1) + NS < sc1;
       st_dma = st_s;
     }
     const unsigned so2 = slab(kc + 2);
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     }
   };
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm1 = __builtin_readcyclecounter();
-  for (int kc = 0; kc < nkc; kc += 2) {
+  for (int kc = kc0; kc < kc1; kc += 2) {
     chunk(kc, C0{});
     chunk(kc + 1, C1{});
   }
@@ -426,9 +438,12 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int rng = t >> 8, run = (t >> 3) & 31, rcg = t & 7;   // reader: channel tile, unit, 4-channel group
   const int ridx = rng * 1024 + run * 8 + (rcg ^ (run & 7));  // + mu * 256
   const int nrd = n0 + rng * 32 + rcg * 4;
-  const float b0 = p.bias[nrd], b1 = p.bias[nrd + 1], b2 = p.bias[nrd + 2], b3 = p.bias[nrd + 3];
+  const bool rawsum = ksp > 1;   // split-K: no bias, no activation, [split][pixel][Cout]
+  const float b0 = rawsum ? 0.f : p.bias[nrd], b1 = rawsum ? 0.f : p.bias[nrd + 1], b2 = rawsum ? 0.f : p.bias[nrd + 2], b3 = rawsum ? 0.f : p.bias[nrd + 3];
   const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
-  float* const orow = p.out + (((size_t)img * p.H + oy) * p.W + ox) * p.ostride + nrd;
+  const int ostr = rawsum ? p.Cout : p.ostride;
+  const bool act = p.leaky && !rawsum;
+  float* const orow = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + oy) * p.W + ox) * ostr + nrd;
   // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
   // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
   // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][68] behind the exchange
@@ -457,14 +472,14 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     for (int c = 0; c < 4; ++c) {
       const float bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
       float v0 = ((m0[c] + m1[c]) + m2[c]) + bv, v1 = ((m1[c] - m2[c]) - m3[c]) + bv;
-      if (p.leaky) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
+      if (act) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
       r0[c] = v0; r1[c] = v1;
     }
     if (p.pw_out == nullptr) {
       if (ox + jx < p.W) {
-        float* const o0 = orow + (size_t)jx * p.ostride;
+        float* const o0 = orow + (size_t)jx * ostr;
         if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
-        if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * p.ostride) = r1;
+        if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * ostr) = r1;
       }
       if (pool_base != nullptr) {
         if (jx & 1) {
@@ -521,7 +536,8 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside; the fused 1x1 adds its [256][68] tile and its weights behind them
   const size_t lds = p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024 : (size_t)3 * 24 * 1024;
   constexpr int NT = 4 * (BN / 32) * 64;
-  if (p.ksize != 3 || p.ksplit > 1 || p.Ctot % 16 || p.Cout % BN) return hipErrorInvalidValue;
+  if (p.ksize != 3 || p.Ctot % 16 || p.Cout % BN) return hipErrorInvalidValue;
+  if (p.ksplit > 1 && (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) || p.Cout % 4 || p.pool_out || p.pw_out || p.ksplit > p.Ctot / 16)) return hipErrorInvalidValue;
   if (p.pw_out) {   // a workgroup must hold every channel of its pixels
     if (BN != 64 || p.Cout != 64 || p.pool_out || p.pw_cout < 1 || p.pw_cout > 4) return hipErrorInvalidValue;
   } else if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
@@ -538,7 +554,7 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
-  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, 1);
+  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();
 }

@@ -594,6 +594,15 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->opt_w2d_min_px = (int)value;
     }
   }
+  else if (!strcmp(key, "w2d_splitk")) {
+    if ((value != 0) != (h->opt_w2d_splitk != 0)) {  // plans carry the split factors: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_w2d_splitk = value != 0;
+    }
+  }
   else if (!strcmp(key, "w2d_shape")) {
     if (value < -1 || value >= W2D_SHAPES) return fail(h, FILM_ERR_INVALID, "w2d_shape: -1 (autotuned) or a Wino2dTile shape index");
     if ((int)value != h->opt_w2d_shape) {  // plans carry the tile choice: drop them

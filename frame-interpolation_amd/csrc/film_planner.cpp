@@ -241,6 +241,22 @@ struct Planner {
         op.part_off = P->bufs[sb].off;
       }
     }
+    // Split-K for the nested kernel (round 5) on the SMALL levels only (<= 4096 pixels per image: the 36x60 level of a 1080p tile - 640
+    // workgroups of its K = 1920 layer on 512 slots - and the 64x64 level of a 256x256 pair, 64-128 workgroups): K >= 768, up to four
+    // K ranges.  Measured (profiles/r05_w2d_splitk.log): K = 1920 @ 8x36x60 0.653 -> 0.531 ms (0.61 -> 0.54 in the forward), K = 1168 @
+    // 1x64x64 0.152 -> 0.084 ms, 256x256 pair 2.91 -> 2.82 ms.  NOT on the 72x120 level: its K = 1920 / 2448 layers are 2304 workgroups
+    // = 4.5 rounds of the 512 slots and two K ranges gain 2-4 % stand-alone, but nothing in the forward (1.84 -> 1.89, 2.48 -> 2.49-2.53
+    // ms per layer with the weights streaming from HBM and the partial sums written and read back: 141 MB for the K = 2448 layer).
+    // No layer with a fused pool / 1x1 head is that deep.  Factor from the level size and the layer only - never the batch.
+    if (h->opt_splitk && h->opt_w2d_splitk && op.wino == 4 && L.cout % 4 == 0) {
+      int S = 1;
+      if (px <= 4096 && ctot >= 768) S = std::min(4, ctot / 384);
+      if (S > 1) {
+        op.ksplit = S;
+        const int sb = add_scratch("splitk:" + op.tag, (int64_t)S * M * L.cout);
+        op.part_off = P->bufs[sb].off;
+      }
+    }
     op.flops = 2.0 * M * L.cout * L.kh * L.kw * L.cin;
     op.bytes = 4.0 * M * (L.cin + L.cout);
     P->ops.push_back(op);

@@ -118,11 +118,16 @@ class Interpolator:
     if engine is not None:
       self._engine = engine
     else:
-      if weights is None:
-        weights = weights_lib.load_weights(model_path, self._options)
-      weights_lib.validate_weights(weights, self._options)
       self._engine = FilmEngine(self._options, device=device)
-      self._engine.set_weights(weights)
+      if weights is None and weights_lib.is_saved_model(model_path):
+        # a TF2 SavedModel directory: the native reader behind the C-ABI (film_load_bundle) replaces
+        # tf.compat.v2.saved_model.load(model_path) (reference :148) - no TensorFlow, no Python parsing
+        self._engine.load_bundle(model_path)
+      else:
+        if weights is None:
+          weights = weights_lib.load_weights(model_path, self._options)
+        weights_lib.validate_weights(weights, self._options)
+        self._engine.set_weights(weights)
     if precision:
       self._engine.set_option('precision', int(precision))
     self._align = align or None

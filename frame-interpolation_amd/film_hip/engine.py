@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_export_layouts', 'film_forward',
     'film_interpolate',
     'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version',
-    'film_export_tune', 'film_import_tune', 'film_to_uint8')
+    'film_export_tune', 'film_import_tune', 'film_to_uint8', 'film_load_bundle')
 
 _lib = None
 
@@ -101,6 +101,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_export_tune.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64, i64p]
     lib.film_import_tune.argtypes = [vp, cp]
     lib.film_to_uint8.argtypes = [vp, vp, ctypes.c_int64, vp]
+    lib.film_load_bundle.argtypes = [vp, cp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, i64p]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ('film_destroy',):
@@ -186,6 +187,27 @@ class FilmEngine:
             self._check(self._lib.film_set_weight(self._h, name.encode(), a.ctypes.data, dims, a.ndim))
         self._check(self._lib.film_finalize(self._h))
         self._load_tune_cache()
+
+    def load_bundle(self, path: str, verify: bool = True) -> Dict[str, Tuple[str, str]]:
+        """film_load_bundle: reads the variables bundle of a Keras SavedModel directory (or a bundle prefix) natively - the
+        replacement of tf.saved_model.load's variable restore, eval/interpolator.py:148 - places every tensor and finalizes.
+        Returns {canonical name: (rule, checkpoint key)}, rule = 'path' | 'shape'; tensors placed by their (unique) shape are
+        logged as a warning (a name match they are not)."""
+        need = ctypes.c_int64()
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self._lib.film_load_bundle(self._h, os.fsencode(path), 1 if verify else 0, buf, len(buf), ctypes.byref(need)))
+        rep = {}
+        for line in buf.value.decode().splitlines():
+            name, rule, key = line.split('\t')
+            rep[name] = (rule, key)
+        by_shape = sorted(n for n, (rule, _) in rep.items() if rule != 'path')
+        if by_shape:
+            import logging
+            logging.getLogger('film_hip.tf_bundle').warning(
+                '%s: %d of %d tensors were not found under a known object-graph path and were placed by their (unique) shape: %s',
+                path, len(by_shape), len(rep), ', '.join(f'{n} <- {rep[n][1]}' for n in by_shape))
+        self._load_tune_cache()
+        return rep
 
     # -- autotune choices across processes ($FILM_TUNE_CACHE = a file path) --------------------------------
     def export_tune(self) -> str:

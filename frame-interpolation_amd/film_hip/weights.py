@@ -143,6 +143,13 @@ def save_weights(model_path: str, weights: Dict[str, np.ndarray]) -> str:
     return fn
 
 
+def is_saved_model(model_path: str) -> bool:
+    """True when `model_path` holds a TF2 SavedModel variables bundle and no film_weights.npz (which load_weights prefers)."""
+    if not model_path or model_path.endswith('.npz') or os.path.isfile(os.path.join(model_path, WEIGHTS_FILE)):
+        return False
+    return os.path.isfile(os.path.join(model_path, 'variables', 'variables.index'))
+
+
 def load_weights(model_path: str, opt: Options = PUBLISHED) -> Dict[str, np.ndarray]:
     """Loads the weight set of a model directory.
 

@@ -222,12 +222,26 @@ int film_get_tap(film_t* h, const char* name, float* dst, int64_t capacity_float
  * current device.  The frames of a recursion then cross PCIe as 1 byte per value instead of 4.  Returns FILM_OK or a negative error. */
 int film_to_uint8(const float* src, unsigned char* dst, int64_t n, void* stream);
 
+/* The variable-restore half of `tf.compat.v2.saved_model.load(model_path)` (reference eval/interpolator.py:148): reads the
+ * checkpoint of a Keras SavedModel - `<path>/variables/variables.index` + `.data-0000N-of-0000M`, written by model.save()
+ * (training/train_lib.py:280, training/build_saved_model_cli.py:65-73) - without TensorFlow and without Python, places every
+ * film_net tensor (film_set_weight) and finalizes the handle (film_finalize).  `path`: the SavedModel directory, or a bundle
+ * prefix (".../variables").  Tensors are found by their Keras object-graph attribute paths (extract_sublevels/convs/i,
+ * _predictors/p/_convs/j, convs/i/j, output_conv - the names in feature_extractor.py:118-123,160, pyramid_flow_estimator.py:
+ * 74-83,111-123, fusion.py:64-101), independent of the layer_with_weights-N numbering; a tensor not found that way is taken
+ * by shape ONLY if its shape is unique among the unplaced tensors and the unused variables - anything ambiguous is an error,
+ * never a guess.  verify_crc != 0 checks the masked crc32c of every index block and tensor.  report (may be NULL) receives
+ * one line per tensor, "<name>\t<path|shape>\t<checkpoint key>\n" (size query: capacity 0, *needed = bytes incl. NUL).
+ * Errors: FILM_ERR_NOTFOUND (no bundle at `path`, a tensor missing), FILM_ERR_INVALID (corrupt / unsupported file, crc). */
+int film_load_bundle(film_t* h, const char* path, int verify_crc, char* report, int64_t report_capacity, int64_t* report_needed);
+
 /* CRC-32C (Castagnoli) continued from `crc` (0 to start) over n bytes.  Host helper of the TF-free SavedModel
  * variables reader (frame-interpolation_amd/film_hip/tf_bundle.py), which checks the masked crc32c TensorFlow
  * stores per tensor and per index block; part of replacing tf.saved_model.load (eval/interpolator.py:148). */
 uint32_t film_crc32c(uint32_t crc, const void* data, int64_t n);
 
-/* Library build info: "gfx950;<build id>" */
+/* Library build info: "gfx950;film_hip r<round>;src=<12 hex digits of the sha1 over csrc/ and this header>[+extra]" ("+extra": built
+ * with FILM_EXTRA_FAMILIES=1, i.e. with the opt-in kernel families).  Tune caches, bench lines and PMC summaries carry it. */
 const char* film_version(void);
 
 #ifdef __cplusplus

@@ -176,12 +176,12 @@ def test_second_weight_set_on_a_used_engine(tiny_weights):
 
 def test_interpolator_from_a_savedmodel_directory(published, tmp_path):
     """Interpolator(model_path=<SavedModel dir>) - variables bundle written with the object-graph keys of a Keras
-    model.save() (film_hip.tf_bundle.save_film_bundle), read back by the TF-free reader - gives the bits of the engine
+    model.save() (tests/bundle_writer.save_film_bundle), read back by the NATIVE reader behind the C-ABI (film_load_bundle) - gives the bits of the engine
     that took the same tensors as a dict."""
+    import bundle_writer
     from eval.interpolator import Interpolator
-    from film_hip import tf_bundle
     opt, w, eng = published
-    tf_bundle.save_film_bundle(str(tmp_path / 'saved_model'), w, opt)
+    bundle_writer.save_film_bundle(str(tmp_path / 'saved_model'), w, opt)
     assert os.path.isfile(tmp_path / 'saved_model' / 'variables' / 'variables.index')
     it = Interpolator(str(tmp_path / 'saved_model'), align=64)
     x0, x1 = TI.frame_pair(1, 120, 200, seed=6)

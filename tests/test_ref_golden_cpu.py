@@ -7,6 +7,8 @@ recursion logic) to the reference's code, and its hand-written op arithmetic to 
 through the whole 7-level recursive network, in float32 and float64.  When tests/golden/tf_*.npz (real TensorFlow,
 `--backend tf`) exist they are used instead and the op semantics are pinned too; until then:
 PARITY WITH TENSORFLOW ITSELF IS UNPINNED (see test_tensorflow_pinning_status)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -201,3 +203,35 @@ def test_tensorflow_pinning_status():
         pytest.skip('parity unpinned against TensorFlow itself: tests/golden/tf_*.npz absent (no TF in this image); '
                     'the ref_*.npz vectors pin the graph to the reference\'s own code over PyTorch built-ins. '
                     'Recipe: python tools/make_ref_golden.py --backend tf')
+
+
+def test_tf_backend_naming_walk_runs_over_the_reference_layers():
+    """`tools/make_ref_golden.py --backend tf` (the recipe for the first TensorFlow-capable machine) assigns the weights to the
+    Keras model by WALKING its layer objects (walk_conv_layers).  No TensorFlow here - but the walk itself can run: over the layer
+    objects the REFERENCE'S OWN create_model builds on oracle/tf_shim.  It must find the 41 Conv2D layers (tiny net: fewer) exactly
+    once, give each the canonical name and object-graph path the shim's weight provider logged while the graph executed (two
+    independent derivations: attribute walk vs call-time name chains), and hand every layer the tensors of that name.
+    Needs /root/reference (present in the build container only)."""
+    import importlib.util
+    from conftest import ROOT
+    if not os.path.isdir('/root/reference/models/film_net'):
+        pytest.skip('the reference checkout is not on this machine')
+    spec = importlib.util.spec_from_file_location('make_ref_golden', os.path.join(ROOT, 'tools', 'make_ref_golden.py'))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    from film_hip import options as O, weights as W
+    ref = mg.Reference('/root/reference', 'shim')
+    w = W.make_synthetic_weights(O.TINY, seed=0)
+    model = ref.model_fn(w, O.TINY)
+    x0, x1 = TI.frame_pair(1, 32, 32, seed=5)
+    model({'x0': x0, 'x1': x1, 'time': np.full((1, 1), 0.5, np.float32)})
+    by_call = {n: (c, p) for n, c, p in model.conv_log}          # names logged while the reference graph executed
+    handed = {}
+    log = mg.walk_conv_layers(ref.tf, model.keras_model.layers, w, lambda layer, k, b: handed.__setitem__(id(layer), (k, b)))
+    assert len(log) == len(w) // 2 == len(by_call) == len(handed)
+    assert {n for n, _, _ in log} == set(by_call) == {n for n, _, _ in W.weight_specs(O.TINY)}
+    for name, chain, path in log:
+        assert by_call[name][1] == path, (name, by_call[name], chain, path)                 # the object-graph path
+        assert chain.startswith('fusion/') or by_call[name][0] == chain == name                # named layers: chain = name
+    for name, _, _ in log:
+        assert any(k is w[name + '/kernel'] and b is w[name + '/bias'] for k, b in handed.values()), name

@@ -7,6 +7,8 @@ import struct
 import numpy as np
 import pytest
 
+import bundle_writer as bw
+
 
 def test_crc32c_known_answers():
     from film_hip import tf_bundle as tb
@@ -32,7 +34,7 @@ def test_table_roundtrip_many_blocks(tmp_path):
              for i in range(500)]
     items.append((b'', b'header'))
     fn = str(tmp_path / 't.index')
-    tb.write_table(fn, items, block_size=512)
+    bw.write_table(fn, items, block_size=512)
     got = tb.read_table(fn)
     assert got == sorted(items)
     raw = open(fn, 'rb').read()
@@ -53,7 +55,7 @@ def test_film_bundle_roundtrip_and_interpolator_load_path(tmp_path, tiny_weights
     from film_hip import weights as W
     from film_hip.options import TINY
     model_dir = str(tmp_path / 'saved_model')
-    prefix = tb.save_film_bundle(model_dir, tiny_weights, TINY)
+    prefix = bw.save_film_bundle(model_dir, tiny_weights, TINY)
     assert os.path.isfile(prefix + '.index') and os.path.isfile(prefix + '.data-00000-of-00001')
     report = {}
     got = tb.load_film_weights(prefix, TINY, report=report)
@@ -112,7 +114,7 @@ def test_shape_fallback_places_only_unambiguous_tensors(tmp_path, tiny_weights):
         tensors[key] = tiny_weights[n]
     tensors['optimizer/iter' + tb.VAR_SUFFIX] = np.zeros((), np.float32)
     prefix = str(tmp_path / 'variables' / 'variables')
-    tb.write_bundle(prefix, tensors, object_graph=False)
+    bw.write_bundle(prefix, tensors, object_graph=False)
     report = {}
     got = tb.load_film_weights(prefix, TINY, report=report)
     assert {n for n, (rule, _) in report.items() if rule == 'shape'} == set(unique)
@@ -120,12 +122,12 @@ def test_shape_fallback_places_only_unambiguous_tensors(tmp_path, tiny_weights):
         assert np.array_equal(got[n], tiny_weights[n]), n
     # all keys unknown: shapes repeat -> refuse, naming the candidates
     tensors = {f'model/variables/{i}{tb.VAR_SUFFIX}': tiny_weights[n] for i, n in enumerate(names)}
-    tb.write_bundle(prefix, tensors, object_graph=False)
+    bw.write_bundle(prefix, tensors, object_graph=False)
     with pytest.raises(ValueError, match='refusing to guess'):
         tb.load_film_weights(prefix, TINY)
     # a missing tensor is still a KeyError
     tensors = {tb.checkpoint_key(n, TINY): tiny_weights[n] for n in names[1:]}
-    tb.write_bundle(prefix, tensors, object_graph=False)
+    bw.write_bundle(prefix, tensors, object_graph=False)
     with pytest.raises(KeyError):
         tb.load_film_weights(prefix, TINY)
 
@@ -193,8 +195,119 @@ def test_shape_placed_tensors_are_logged(tmp_path, tiny_weights, caplog):
     odd = next(n for n in names if shapes.count(tuple(tiny_weights[n].shape)) == 1)
     tensors = {(f'model/variables/0{tb.VAR_SUFFIX}' if n == odd else tb.checkpoint_key(n, TINY)): tiny_weights[n] for n in names}
     prefix = str(tmp_path / 'variables' / 'variables')
-    tb.write_bundle(prefix, tensors, object_graph=False)
+    bw.write_bundle(prefix, tensors, object_graph=False)
     with caplog.at_level(logging.WARNING, logger='film_hip.tf_bundle'):
         got = tb.load_film_weights(prefix, TINY)
     assert np.array_equal(got[odd], tiny_weights[odd])
     assert len(caplog.records) == 1 and odd in caplog.records[0].getMessage() and 'placed by their (unique) shape' in caplog.records[0].getMessage()
+
+
+# ---- the native reader behind the C-ABI (film_load_bundle, csrc/film_bundle.cpp) against both writers and the Python reader ----------
+def _native(opt):
+    from film_hip.engine import FilmEngine
+    return FilmEngine(opt, device=-1)       # plan-only handle: packs weights, no GPU needed
+
+
+def test_native_loader_reads_both_writers_like_the_python_reader(tmp_path, tiny_weights, caplog):
+    """film_load_bundle(<SavedModel dir>) = tf.saved_model.load's variable restore (eval/interpolator.py:148) without Python: on the
+    bundle of tests/bundle_writer.py AND on the TensorFlow-like one of tests/tf_like_writer.py (two shards, multi-block index with
+    prefix compression, Adam slots of identical shapes, int64 counters, a real object graph) the handle ends up with exactly the
+    parameter blob of a handle that took the Python reader's arrays, every tensor placed by its path."""
+    import logging
+    import tf_like_writer as tw
+    from film_hip import tf_bundle as tb
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    ref = _native(TINY)
+    ref.set_weights(tiny_weights)
+    want = ref.export_packed()
+    d1 = tmp_path / 'a'
+    bw.save_film_bundle(str(d1), tiny_weights, TINY)
+    d2 = tmp_path / 'b'
+    full = {tb.checkpoint_key(n, TINY)[:-len(tb.VAR_SUFFIX)]: n for n in tiny_weights}
+    tw.write_tf_like_bundle(str(d2 / 'variables' / 'variables'), _paths(tiny_weights, TINY), full_names=full, num_shards=2, block_size=384)
+    for path in (str(d1), str(d2), str(d2 / 'variables' / 'variables'), str(d2 / 'variables' / 'variables.index')):
+        eng = _native(TINY)
+        with caplog.at_level(logging.WARNING, logger='film_hip.tf_bundle'):
+            rep = eng.load_bundle(path)
+        assert not caplog.records
+        assert set(rep) == set(tiny_weights) and all(rule == 'path' for rule, _ in rep.values())
+        py = {}
+        tb.load_film_weights(path[:-6] if path.endswith('.index') else (path if not os.path.isdir(path) else os.path.join(path, 'variables', 'variables')), TINY, report=py)
+        assert {n: k for n, (_, k) in rep.items()} == {n: k for n, (_, k) in py.items()}      # same variable for every tensor
+        assert np.array_equal(eng.export_packed(), want)
+        assert eng.plan(1, 64, 64)['ops']                                                     # finalized: plans can be built
+        eng.close()
+    ref.close()
+
+
+def test_native_loader_errors_and_shape_rule(tmp_path, tiny_weights, caplog):
+    """Same rules as the Python reader: unique shapes may be placed by shape (and that is logged), repeated shapes are refused with
+    the candidates named, a missing tensor / a missing bundle is FILM_ERR_NOTFOUND, a flipped payload or index byte is a crc error."""
+    import logging
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.engine import FilmError
+    from film_hip.options import TINY
+    names = [n for spec, _, _ in W.weight_specs(TINY) for n in (spec + '/kernel', spec + '/bias')]
+    shapes = [tuple(tiny_weights[n].shape) for n in names]
+    unique = [n for n in names if shapes.count(tuple(tiny_weights[n].shape)) == 1]
+    prefix = str(tmp_path / 'variables' / 'variables')
+    tensors = {(f'model/variables/{i}{tb.VAR_SUFFIX}' if n in unique else tb.checkpoint_key(n, TINY)): tiny_weights[n] for i, n in enumerate(names)}
+    tensors['optimizer/iter' + tb.VAR_SUFFIX] = np.zeros((), np.float32)
+    bw.write_bundle(prefix, tensors, object_graph=False)
+    ref = _native(TINY)
+    ref.set_weights(tiny_weights)
+    eng = _native(TINY)
+    with caplog.at_level(logging.WARNING, logger='film_hip.tf_bundle'):
+        rep = eng.load_bundle(str(tmp_path))
+    assert {n for n, (rule, _) in rep.items() if rule == 'shape'} == set(unique)
+    assert len(caplog.records) == 1 and 'placed by their (unique) shape' in caplog.records[0].getMessage()
+    assert np.array_equal(eng.export_packed(), ref.export_packed())
+    # flipped payload byte -> per-tensor crc; verify=False reads it anyway
+    fn = prefix + '.data-00000-of-00001'
+    raw = bytearray(open(fn, 'rb').read())
+    raw[10] ^= 0x40
+    open(fn, 'wb').write(raw)
+    with pytest.raises(FilmError, match='crc32c'):
+        _native(TINY).load_bundle(str(tmp_path))
+    _native(TINY).load_bundle(str(tmp_path), verify=False)
+    # flipped index byte -> block crc; truncated file -> magic
+    idx = bytearray(open(prefix + '.index', 'rb').read())
+    idx[20] ^= 1
+    open(prefix + '.index', 'wb').write(idx)
+    with pytest.raises(FilmError, match='crc32c'):
+        _native(TINY).load_bundle(str(tmp_path))
+    open(prefix + '.index', 'wb').write(bytes(idx[:-1]) + b'\x00')
+    with pytest.raises(FilmError, match='magic'):
+        _native(TINY).load_bundle(str(tmp_path))
+    # all keys unknown: shapes repeat -> refuse, naming the candidates
+    bw.write_bundle(prefix, {f'model/variables/{i}{tb.VAR_SUFFIX}': tiny_weights[n] for i, n in enumerate(names)}, object_graph=False)
+    with pytest.raises(FilmError, match='refusing to guess'):
+        _native(TINY).load_bundle(str(tmp_path))
+    # a missing tensor / no bundle at all: FILM_ERR_NOTFOUND (-6)
+    bw.write_bundle(prefix, {tb.checkpoint_key(n, TINY): tiny_weights[n] for n in names[1:]}, object_graph=False)
+    with pytest.raises(FilmError, match='no variable found') as ei:
+        _native(TINY).load_bundle(str(tmp_path))
+    assert ei.value.code == -6
+    with pytest.raises(FilmError, match='no SavedModel variables bundle') as ei:
+        _native(TINY).load_bundle(str(tmp_path / 'nothing_here'))
+    assert ei.value.code == -6
+
+
+def test_interpolator_takes_the_native_path_for_a_savedmodel_directory(tmp_path, tiny_weights, monkeypatch):
+    """eval.interpolator.Interpolator(<SavedModel dir>) goes through film_load_bundle - not through the Python parser."""
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.options import TINY
+    d = tmp_path / 'saved_model'
+    bw.save_film_bundle(str(d), tiny_weights, TINY)
+    assert W.is_saved_model(str(d)) and not W.is_saved_model(str(tmp_path)) and not W.is_saved_model('')
+    W.save_weights(str(tmp_path / 'npz'), tiny_weights)
+    assert not W.is_saved_model(str(tmp_path / 'npz'))
+    monkeypatch.setattr(tb, 'load_film_weights', lambda *a, **k: (_ for _ in ()).throw(AssertionError('python parser used')))
+    from eval.interpolator import Interpolator
+    it = Interpolator(str(d), align=64, options=TINY, device=-1)
+    ref = _native(TINY)
+    ref.set_weights(tiny_weights)
+    assert np.array_equal(it.engine.export_packed(), ref.export_packed())

@@ -119,8 +119,52 @@ class _ShimModel:
         x0, x1, t = (tf.convert_to_tensor(inputs[k]) for k in ('x0', 'x1', 'time'))
         m = self.ref.model.create_model(x0, x1, t, self.config)
         self.conv_log = used
+        self.keras_model = m
         self.layers = [l.name for l in m.layers]
         return m.outputs
+
+
+def walk_conv_layers(tf, top_layers, weights, on_conv):
+    """The `--backend tf` naming walk: every Conv2D reachable from the three top-level Keras layers of create_model
+    (feat_net, predict_flow, fusion) through instance attributes and (nested) lists - i.e. along the edges Keras' object graph
+    tracks - gets its canonical name from its name chain (named layers) / attribute path (the decoder's unnamed ones) and is
+    handed to on_conv(layer, kernel, bias); first owner wins (the shared flow predictor is listed four times).  Returns
+    [(canonical name, name chain, attribute path)].  Written against tf.keras; tests/test_ref_golden_cpu.py runs it over
+    oracle/tf_shim's layer objects, where it must reproduce the names the shim's own weight provider logged."""
+    conv_log, seen = [], set()
+
+    def walk(obj, chain, path):
+        for attr, val in list(vars(obj).items()):
+            items = [(attr, val)]
+            if isinstance(val, (list, tuple)):
+                items = []
+                stack = [(attr, val)]
+                while stack:
+                    p, seq = stack.pop()
+                    for i, v in enumerate(seq):
+                        if isinstance(v, (list, tuple)):
+                            stack.append((f'{p}/{i}', v))
+                        else:
+                            items.append((f'{p}/{i}', v))
+            for p, v in items:
+                if isinstance(v, tf.keras.layers.Conv2D):
+                    if id(v) in seen:
+                        continue
+                    seen.add(id(v))
+                    named = bool(v.name) and not v.name.startswith('conv2d')     # (Keras auto-names unnamed layers conv2d_<n>; the shim leaves None)
+                    ch = f'{chain}/{v.name}' if named else f'{chain}/{p.split("/")[0]}'
+                    name = canonical_name(ch, f'{path}/{p}' if path else p)
+                    on_conv(v, weights[name + '/kernel'], weights[name + '/bias'])
+                    conv_log.append((name, ch, f'{path}/{p}' if path else p))
+                elif isinstance(v, tf.keras.layers.Layer) and not attr.startswith('_keras'):
+                    if id(v) in seen:
+                        continue
+                    seen.add(id(v))
+                    walk(v, f'{chain}/{v.name or p.split("/")[0]}', f'{path}/{p}' if path else p)
+    for layer in top_layers:
+        if layer.name in ('feat_net', 'predict_flow', 'fusion'):
+            walk(layer, layer.name, '')
+    return conv_log
 
 
 class _TfModel:
@@ -130,40 +174,7 @@ class _TfModel:
         x1 = tf.keras.Input(shape=(None, None, 3), dtype=tf.float32, name='x1')
         t = tf.keras.Input(shape=(1,), dtype=tf.float32, name='time')
         self.m = ref.model.create_model(x0, x1, t, config)
-        self.conv_log = []
-
-        def walk(obj, chain, path):
-            for attr, val in list(vars(obj).items()):
-                items = [(attr, val)]
-                if isinstance(val, (list, tuple)):
-                    items = []
-                    stack = [(attr, val)]
-                    while stack:
-                        p, seq = stack.pop()
-                        for i, v in enumerate(seq):
-                            if isinstance(v, (list, tuple)):
-                                stack.append((f'{p}/{i}', v))
-                            else:
-                                items.append((f'{p}/{i}', v))
-                for p, v in items:
-                    if isinstance(v, tf.keras.layers.Conv2D):
-                        if id(v) in seen:
-                            continue
-                        seen.add(id(v))
-                        named = not v.name.startswith('conv2d')
-                        ch = f'{chain}/{v.name}' if named else f'{chain}/{p.split("/")[0]}'
-                        name = canonical_name(ch, f'{path}/{p}' if path else p)
-                        v.set_weights([weights[name + '/kernel'], weights[name + '/bias']])
-                        self.conv_log.append((name, ch, p))
-                    elif isinstance(v, tf.keras.layers.Layer) and not attr.startswith('_keras'):
-                        if id(v) in seen:
-                            continue
-                        seen.add(id(v))
-                        walk(v, f'{chain}/{v.name}', f'{path}/{p}' if path else p)
-        seen = set()
-        for layer in self.m.layers:
-            if layer.name in ('feat_net', 'predict_flow', 'fusion'):
-                walk(layer, layer.name, '')
+        self.conv_log = walk_conv_layers(tf, self.m.layers, weights, lambda layer, k, b: layer.set_weights([k, b]))
         assert len(self.conv_log) == len(weights) // 2, (len(self.conv_log), len(weights) // 2)
         self.layers = [l.name for l in self.m.layers]
 

@@ -1,6 +1,7 @@
-// w2d_bench.hip -- micro-benchmark + bit-identity check of the nested-Winograd kernels (round 3's conv_wino2d_r3_kernel tiles against
-// conv_wino2d_kernel) on the layer shapes they run in a 1080p 2x2-tiled forward, plus a two-segment input with a batch remap
-// and a ragged level.  Development tool (lean sibling of conv_bench.hip: compiles in a minute), not part of the product library.
+// w2d_bench.hip -- micro-benchmark + bit-identity check of the nested-Winograd kernel conv_wino2d_kernel (its tiles against each other;
+// the W2D_F_XFIRST variants keep the summation order - and the bits - of round 3's kernel, which left the tree in round 5) and of its
+// split-K form against the unsplit result, with the 1-D F(4,3) kernel as the timing reference, on the layer shapes they run in a 1080p
+// 2x2-tiled forward, plus a two-segment input with a batch remap and ragged levels.  Development tool (lean sibling of conv_bench.hip: compiles in a minute), not part of the product library.
 //
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off tools/w2d_bench.hip -o tools/bin/w2d_bench
 //   tools/bin/w2d_bench [reps] [shape index | -1] [variant substring[,substring...]]
@@ -13,7 +14,6 @@
 #include <string>
 #include <vector>
 
-#include "retired/conv_wino2d_r3_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino43_impl.h"
 #include "../frame-interpolation_amd/csrc/conv_wino2d_impl.h"
 
@@ -93,22 +93,51 @@ __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* 
 }
 
 typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
-// fam 0: the bits of round 3's conv_wino2d_r3_kernel (reference = the first variant run); fam 1: conv_wino2d_kernel's own family (reference = the
+// fam 3: split-K (its own sums: the distance from family 1 is printed, never counted as a mismatch);
+// fam 0: the bits of round 3's kernel (the W2D_F_XFIRST order; reference = the first variant run); fam 1: conv_wino2d_kernel's own family (reference = the
 // first fam-1 variant run; its distance from family 0 is printed); fam -1: timing ablation (wrong on purpose); fam 2: the 1-D F(4,3)
 // kernel conv_wino43_kernel (its own weights and sums: timing reference, distance from family 0 printed)
 struct Variant { const char* name; int bn; int fam; LaunchFn fn; };
-constexpr int SCHED = W2R_F_ILV | W2R_F_LATE | W2R_F_B2;
-constexpr int MIDF = W2R_F_ILV | W2R_F_B2 | W2R_F_MIDBAR;
-#define W2D(NAME, BN, FL) {"r3  " NAME, BN, 0, conv_wino2d_r3_launch<8, BN, FL, 8>}
 #define W2N(NAME, BN, FL) {"w2d " NAME, BN, ((FL) & 0x3F00) ? -1 : ((FL) & W2D_F_XFIRST) ? 0 : 1, conv_wino2d_launch<BN, FL>}
+// split-K: conv_wino2d_kernel with S K ranges (blockIdx.z) + the ordered reduction (the engine's conv_splitk_reduce_kernel, restated)
+static float* g_part = nullptr;
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                            int M, int Cout, int ostride, int S, int leaky) {
+  const int G = Cout >> 2;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (unsigned)M * (unsigned)G) return;
+  const unsigned m = idx / (unsigned)G, g = idx - m * (unsigned)G;
+  const size_t plane = (size_t)M * Cout;
+  const float4* src = reinterpret_cast<const float4*>(part + (size_t)m * Cout + g * 4);
+  float4 a = *reinterpret_cast<const float4*>(bias + g * 4);
+  for (int sidx = 0; sidx < S; ++sidx) {
+    const float4 v = src[(size_t)sidx * (plane >> 2)];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (leaky) {
+    a.x = a.x > 0.f ? a.x : 0.2f * a.x; a.y = a.y > 0.f ? a.y : 0.2f * a.y;
+    a.z = a.z > 0.f ? a.z : 0.2f * a.z; a.w = a.w > 0.f ? a.w : 0.2f * a.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)m * ostride + g * 4) = a;
+}
+template <int BN, int S>
+static hipError_t w2d_split(const ConvParams& p0, hipStream_t st) {
+  ConvParams p = p0;
+  p.ksplit = S; p.part = g_part;
+  const hipError_t e = conv_wino2d_launch<BN, 4>(p, st);
+  if (e != hipSuccess) return e;
+  const unsigned units = (unsigned)p.M * (unsigned)(p.Cout >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((units + 255) / 256), dim3(256), 0, st, p.part, p.bias, p.out, p.M, p.Cout, p.ostride, S, p.leaky);
+  return hipGetLastError();
+}
+#define W2S(NAME, BN, S) {"w2d " NAME, BN, 3, w2d_split<BN, S>}
 #define W43(NAME, BN, ...) {"w43 " NAME, BN, 2, conv_wino43_launch<__VA_ARGS__>}
 static Variant variants[] = {
-    W2D("8x64_RM", 64, 4 | MIDF | W2R_F_RAW), W2D("8x32_R", 32, 4 | SCHED | W2R_F_RAW), W2D("8x32_M", 32, 4 | MIDF), W2D("8x64_R", 64, 4 | SCHED | W2R_F_RAW),
-    W2D("8x64_RM plain", 64, MIDF | W2R_F_RAW), W2D("8x32_R plain", 32, SCHED | W2R_F_RAW),
     W43("q16 4x64 t21 p2", 64, 4, 64, 2, 1, 4 | W43_F_PF2, 16), W43("q16 4x64 n1 p2", 64, 4, 64, 1, 1, 4 | W43_F_PF2, 16, 1), W43("q8 8x64 t21 p2", 64, 8, 64, 2, 1, 4 | W43_F_PF2, 8),
     W43("q8 8x64 n1 p2", 64, 8, 64, 1, 1, 4 | W43_F_PF2, 8, 1), W43("q16 4x32 bg", 32, 4, 32, 1, 1, 4 | W43_F_BG, 16), W43("q8 8x32 bg", 32, 8, 32, 1, 1, 4 | W43_F_BG, 8), W43("q8 8x32 p2", 32, 8, 32, 1, 1, 4 | W43_F_PF2, 8),
     W2N("64 xf", 64, 4 | W2D_F_XFIRST), W2N("32 xf", 32, 4 | W2D_F_XFIRST),
     W2N("64", 64, 4), W2N("32", 32, 4), W2N("64 plain", 64, 0), W2N("32 plain", 32, 0),
+    W2S("64 split2", 64, 2), W2S("32 split2", 32, 2), W2S("64 split3", 64, 3), W2S("32 split3", 32, 3), W2S("64 split4", 64, 4), W2S("32 split4", 32, 4),
     W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
     W2N("64 abl-noxf", 64, 4 | W2D_DBG_NOXF), W2N("32 abl-noxf", 32, 4 | W2D_DBG_NOXF),
     W2N("64 abl-nodma", 64, 4 | W2D_DBG_NODMA), W2N("32 abl-nodma", 32, 4 | W2D_DBG_NODMA),
@@ -143,6 +172,9 @@ static Shape shapes[] = {
     {"fusion_0_2  4x576x960   64->64", 4, 576, 960, 64, 64, 0},
     {"fusion_1_2  4x288x480  128->128", 4, 288, 480, 128, 128, 0},
     {"two-seg     4x144x240  (96|48)->64, batch halves swapped in seg 1", 4, 144, 240, 144, 64, 48},
+    {"flow_l4_c0  8x36x60   1920->256", 8, 36, 60, 1920, 256, 0},
+    {"256:fus_2_1 1x64x64   1168->256", 1, 64, 64, 1168, 256, 0},
+    {"two-seg deep 2x72x120 (1040|880)->256, batch halves swapped in seg 1", 2, 72, 120, 1920, 256, 880},
     {"ragged      3x36x60    64->64", 3, 36, 60, 64, 64, 0},
     {"ragged2     2x50x70    (32|16)->32", 2, 50, 70, 48, 32, 16},
 };
@@ -174,6 +206,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&d_ref, n_out * 4));
     CK(hipMalloc(&d_ref1, n_out * 4));
     CK(hipMalloc(&d_md, 4));
+    CK(hipMalloc(&g_part, n_out * 4 * 4));
     CK(hipMalloc(&d_b, sh.Cout * 4));
     CK(hipMalloc(&d_out, n_out * 4));
     hipLaunchKernelGGL(fill_kernel, dim3(4096), dim3(256), 0, st, d_a, n_a, 1u, 1.0f);
@@ -204,7 +237,7 @@ int main(int argc, char** argv) {
         std::string flt(only_variant);
         for (size_t b = 0; b <= flt.size();) {
           const size_t e = flt.find(',', b) == std::string::npos ? flt.size() : flt.find(',', b);
-          if (e > b && strstr(v.name, flt.substr(b, e - b).c_str())) hit = true;
+          if (e > b && (flt[b] == '=' ? flt.substr(b + 1, e - b - 1) == v.name : strstr(v.name, flt.substr(b, e - b).c_str()) != nullptr)) hit = true;   // "=name": exact
           b = e + 1;
         }
         if (!hit) continue;
@@ -228,9 +261,11 @@ int main(int argc, char** argv) {
         CK(hipStreamSynchronize(st));
         return md;
       };
-      const int fam = v.fam < 0 ? 1 : v.fam;   // (ablations are variants of the y-first loop)
+      const int fam = v.fam < 0 ? 1 : v.fam == 3 ? 1 : v.fam;   // (ablations are variants of the y-first loop)
       float* const refs[2] = {d_ref, d_ref1};
-      if (v.fam == 2) {
+      if (v.fam == 3) {
+        if (have_ref[1]) fam_dist = diff_to(d_ref1);
+      } else if (v.fam == 2) {
         if (have_ref[0]) fam_dist = diff_to(d_ref);
       } else if (v.fam >= 0 && !have_ref[fam]) {
         have_ref[fam] = true;
@@ -266,13 +301,14 @@ int main(int argc, char** argv) {
       }
       const bool abl = v.fam < 0;
       if (!abl && maxdiff != 0.f) ++bad;
+      if (v.fam == 3 && have_ref[1] && !(fam_dist < 1e-2f)) ++bad;   // a split-K result far from the unsplit one (wrong range / cursor)
       printf("   %-24s  min %8.3f ms  avg %8.3f ms  %7.1f TF/s direct-eq  %s max|d| %.2e", v.name, best, tot / reps, flops / best * 1e-9,
-             abl ? "(ablation)" : v.fam == 2 ? "1-D family" : maxdiff == 0.f ? (fam ? "bit-identical (family 1)" : "bit-identical (family 0)") : "MISMATCH", maxdiff);
-      if (fam_dist >= 0.f) printf("   [vs family 0: max|d| %.2e, checksum %.6e]", fam_dist, sum);
+             abl ? "(ablation)" : v.fam == 3 ? "split-K family" : v.fam == 2 ? "1-D family" : maxdiff == 0.f ? (fam ? "bit-identical (family 1)" : "bit-identical (family 0)") : "MISMATCH", maxdiff);
+      if (fam_dist >= 0.f) printf("   [vs family %d: max|d| %.2e, checksum %.6e]", v.fam == 3 ? 1 : 0, fam_dist, sum);
       printf("\n");
       fflush(stdout);
     }
-    CK(hipFree(d_tm));
+    CK(hipFree(d_tm)); CK(hipFree(g_part)); g_part = nullptr;
     CK(hipFree(d_a)); if (d_bb) CK(hipFree(d_bb)); CK(hipFree(d_w)); CK(hipFree(d_w2d)); CK(hipFree(d_w43)); CK(hipFree(d_ref)); CK(hipFree(d_ref1)); CK(hipFree(d_md)); CK(hipFree(d_b)); CK(hipFree(d_out));
   }
   printf("mismatches: %d\n", bad);
