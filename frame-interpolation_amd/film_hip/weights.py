@@ -173,8 +173,9 @@ def load_weights(model_path: str, opt: Options = PUBLISHED) -> Dict[str, np.ndar
 
 def main(argv=None) -> int:
     """``python -m film_hip.weights <model dir | film_weights.npz> --export blob.bin``: the parameter set as the flat float32
-    blob of ``film_export_packed`` (per layer the HWIO kernel, then the bias) - what a C / C++ host hands to
-    ``film_import_packed``; the SavedModel reader itself stays on the Python side."""
+    blob of ``film_export_packed`` (per layer the HWIO kernel, then the bias) - what a host hands to ``film_import_packed``
+    (e.g. the ranks of a multi-GPU job).  A C / C++ host can also read the SavedModel directly: ``film_load_bundle``
+    (INTEGRATION.md 2)."""
     import argparse
     ap = argparse.ArgumentParser(prog='python -m film_hip.weights')
     ap.add_argument('model_path')

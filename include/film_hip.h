@@ -133,7 +133,9 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "graph"   0/1  replay the plan as a hipGraph (default 1)
  *   "profile" 0/1  record a hipEvent pair around every kernel of the next forwards
  *                  (forces graph off); read the result with film_profile_json
- *   "precision" p  0 (default): every convolution on the exact fp32 MFMA.  1: "bf16x6" - the large 3x3
+ *   (options marked [extra] exist only in a library built with FILM_EXTRA_FAMILIES=1 - libfilm_hip_extra.so, see film_version();
+ *   the default library, which holds only the kernel families a default plan can select, refuses them with a message)
+ *   "precision" p  [extra for 1, 2]  0 (default): every convolution on the exact fp32 MFMA.  1: "bf16x6" - the large 3x3
  *                  convolutions split each fp32 operand exactly into three bf16 pieces and accumulate the six
  *                  partial products >= 2^-16 in fp32 on the bf16 matrix pipe (dropped terms < 2^-23 relative);
  *                  about 1.5x faster, results differ from mode 0 at the level of a changed summation order.
@@ -174,15 +176,18 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "winograd" w   1 (default): the large 3x3 convolutions use a 1-D Winograd transform along x - F(4,3) (2x fewer
  *                  fp32 multiplies, 128-pixel patches) on the levels whose width fills its patches, F(2,3) (1.5x fewer)
  *                  elsewhere; fp32 throughout, the rounding differs from the direct sum at the 1e-6 (F(2,3)) /
- *                  5e-6 (F(4,3)) level.  0: direct kernels only.  2 / 3: F(2,3) / F(4,3) on every eligible 3x3
+ *                  5e-6 (F(4,3)) level.  0: direct kernels only.  2 [extra] / 3: F(2,3) / F(4,3) on every eligible 3x3
  *                  convolution (tests).  Changing it drops the cached plans.
- *   "halo_all" 0/1 run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
+ *   "halo_all" 0/1 [extra] run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.
  *   "wino2d"  0/1/2  1 (default): the deep-K 3x3 convolutions (>= 208 input channels, or 128 -> 32) of levels with >= 8192 pixels run the nested
  *                  Winograd form F(4,3) along x times F(2,3) along y (conv_wino2d_kernel: 3 multiplies per output where the 1-D
  *                  F(4,3) kernel spends 4.5 and the direct convolution 9; fp32 throughout, rounding at the level of the 1-D form).
  *                  0: never.  2: every layer that has the weight copy, on every level (tests).  Drops the cached plans.
+ *   "w2d_splitk" 0/1  1 (default): the nested kernel's K >= 768 layers on levels of <= 4096 pixels per image (the 36x60 level of a 1080p
+ *                  tile, the 64x64 level of a 256x256 pair) run as up to four K ranges + the ordered reduction, like "splitk"
+ *                  (which also switches it off); factor from the level size and the layer only.  Drops the cached plans.
  *   "w43_shape" n  test knob: every convolution on conv_wino43_kernel that can run tile shape n (Wino43Tile, film_kernels.h)
  *                  does, instead of the autotuned shape; -1 (default) = autotuned.  Results cannot change.  Drops the cached plans.
  *   "w2d_shape" n  the same for conv_wino2d_kernel (Wino2dTile).

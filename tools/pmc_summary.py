@@ -113,7 +113,22 @@ def main():
     else:
         print('\n'.join(lines))
     if args.json and 'conv_mfma' in js:
-        out = {'source': f'{args.md or args.dir} ({args.command}, last forward)', 'kernel': 'conv class: conv_wino2d (dominant) / conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf (+ split-K reduce) + first-layer conv_c3 / conv_igemm',
+        # which build of the kernels the counters belong to: the bench line every pass printed carries film_version() (a hash of
+        # csrc/ + the public header); bench.py replays roofline.traffic from this file ONLY when its own build string is the same
+        build = None
+        for pname in ('fetch', 'write', 'sq1', 'sq2', 'tcc1'):
+            log = os.path.join(args.dir, pname + '.log')
+            if os.path.isfile(log):
+                for line in open(log, errors='replace'):
+                    if line.startswith('{"metric"'):
+                        try:
+                            b = json.loads(line).get('build')
+                        except ValueError:
+                            continue
+                        if build is not None and b != build:
+                            raise SystemExit(f'{log}: build {b} differs from the other passes ({build})')
+                        build = b
+        out = {'build': build, 'source': f'{args.md or args.dir} ({args.command}, last forward)', 'kernel': 'conv class: conv_wino2d (dominant) / conv_wino43 / conv_buf (+ split-K reduce) + first-layer conv_c3',
                'fetch_correction': 2.0, 'classes': js, 'hbm_bytes_per_launch': js['conv_mfma'].get('hbm_bytes_per_launch'),
                'note': 'FETCH_SIZE doubled per MI355X_MICROARCH.md; Infinity-Cache hits are included in these counters'}
         json.dump(out, open(args.json, 'w'), indent=1)
