@@ -360,7 +360,8 @@ def main():
                     help='weak (default): every rank interpolates its own frame pairs; strong: ONE pair, its tiles sharded over '
                          'the ranks for the whole recursion tree, generated tiles gathered to rank 0 inside the timed region')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='one stream, plan order (option graph = 0)')
+    ap.add_argument('--graph', action='store_true', help='hipGraph replay of the two lanes (option graph = 1) instead of the default direct two-lane launches')
     ap.add_argument('--lanes', type=int, default=1, choices=[0, 1, 2],
                     help='0: replay the graph on ONE stream (serialised kernels: what the committed rocprofv3 kernel trace uses, '
                          'so that per-kernel durations are not inflated by overlap); 1: two-stream graph, decoder behind the flow '
@@ -438,6 +439,8 @@ def main():
         eng.set_option('tune_ms', int(os.environ['FILM_TUNE_MS']))
     if args.no_graph:
         eng.set_option('graph', 0)
+    elif args.graph:
+        eng.set_option('graph', 1)
     if args.lanes != 1:
         eng.set_option('lanes', args.lanes)
     if args.wino2d is not None:
@@ -719,7 +722,7 @@ def main():
                                        f'one gather of the generated tiles to rank 0 per step (timed); weights RCCL-broadcast once') if strong
                                       else f'{world} independent GPU(s), weights RCCL-broadcast once',
                        'roofline_profiled_on': f'one model invocation of {prof["B"]} tile(s) / pair(s) of {prof["W"]}x{prof["H"]}',
-                       'graph': not args.no_graph, 'lanes': args.lanes},
+                       'exec': 'one stream' if args.no_graph else 'hipGraph replay' if args.graph else 'direct launches, two lanes', 'lanes': args.lanes},
             'parity': parity,
             'timed_output_bit_identical_to_first_call': timed_same,
             'build': eng.version(),

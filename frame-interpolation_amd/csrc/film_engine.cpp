@@ -494,7 +494,10 @@ const char* film_last_error(const film_t* h) { return h ? h->err.c_str() : g_cre
 
 int film_set_option(film_t* h, const char* key, int64_t value) {
   if (!h || !key) return FILM_ERR_INVALID;
-  if (!strcmp(key, "graph")) h->opt_graph = value != 0;
+  if (!strcmp(key, "graph")) {
+    if (value < 0 || value > 2) return fail(h, FILM_ERR_INVALID, "graph: 0 (one stream, eager), 1 (hipGraph replay) or 2 (two lanes, eager: the default)");
+    h->opt_graph = (int)value;
+  }
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
@@ -832,6 +835,47 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
 }
 
 namespace {
+// The plan's ops on two lanes: lane 0 on `main`, lane 1 (small subtrees, coarse flow levels, the t = 0.5 warps) on the handle's side
+// stream, forked from and joined to `main`; cross-lane ordering = the events found by Planner::analyze_lanes (each op is waited for
+// at most once by the other lane - see there for why that matters to a graph replay).  Called inside a stream capture (graph = 1:
+// the events become graph edges) or directly (graph = 2: real events; one set per plan, re-recorded every forward - a wait refers
+// to the record that precedes it in program order, and everything of forward n + 1 is ordered behind forward n's join on `main`).
+hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main) {
+  const size_t nops = P->ops.size();
+  if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
+  hipError_t ev_err = hipSuccess;
+  auto event_of = [&](size_t i) -> hipEvent_t {
+    if (!P->lane_ev[i]) {
+      hipError_t e = hipEventCreateWithFlags(&P->lane_ev[i], hipEventDisableTiming);
+      if (e != hipSuccess) { ev_err = e; P->lane_ev[i] = nullptr; }
+    }
+    return P->lane_ev[i];
+  };
+  const bool two_lanes = h->opt_lanes != 0;
+  hipError_t le = hipSuccess;
+  if (two_lanes) {
+    le = hipEventRecord(event_of(nops), main);
+    if (le == hipSuccess) le = hipStreamWaitEvent(h->stream2, event_of(nops), 0);
+  }
+  for (size_t i = 0; i < nops && le == hipSuccess; ++i) {
+    const OpDesc& op = P->ops[i];
+    const int lane = (two_lanes && op.lane == 1) ? 1 : 0;
+    hipStream_t ls = lane ? h->stream2 : main;
+    if (two_lanes)
+      for (int d : op.xdeps) {
+        le = hipStreamWaitEvent(ls, event_of((size_t)d), 0);
+        if (le != hipSuccess) break;
+      }
+    if (le == hipSuccess) le = launch_op(op, P->arena, h->packed_dev, ls);
+    if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
+  }
+  if (two_lanes && le == hipSuccess) {
+    le = hipEventRecord(event_of(nops + 1), h->stream2);
+    if (le == hipSuccess) le = hipStreamWaitEvent(main, event_of(nops + 1), 0);
+  }
+  return le == hipSuccess ? ev_err : le;
+}
+
 // Executes the plan on stream s (inputs already in the plan's img0 buffer, result left in its out buffer).
 int run_plan(film_t* h, Plan* P, hipStream_t s) {
   const int B = P->B, H = P->H, W = P->W;
@@ -865,53 +909,23 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
     }
     o << "},\"ops\":[" << ops.str() << "]}";
     h->profile_json = o.str();
-  } else if (h->opt_graph) {
+  } else if (h->opt_graph == 1) {
     if (!P->graph_exec) {
       // capture on the handle's own stream, replay on whichever stream the caller wants
       HIPCHK(h, hipStreamSynchronize(s));
-      // two capture streams: lane 1 (small subtrees, coarse flow levels, the t = 0.5 warps) forks from and joins
-      // the main stream; cross-lane ordering = the events found by Planner::analyze_lanes (each op is waited for at
-      // most once by the other lane - see there for why that matters to the replay)
-      const size_t nops = P->ops.size();
-      if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
-      hipError_t ev_err = hipSuccess;
-      auto event_of = [&](size_t i) -> hipEvent_t {
-        if (!P->lane_ev[i]) {
-          hipError_t e = hipEventCreateWithFlags(&P->lane_ev[i], hipEventDisableTiming);
-          if (e != hipSuccess) { ev_err = e; P->lane_ev[i] = nullptr; }
-        }
-        return P->lane_ev[i];
-      };
-      const bool two_lanes = h->opt_lanes != 0;
       HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      hipError_t le = hipSuccess;
-      if (two_lanes) {
-        le = hipEventRecord(event_of(nops), h->stream);
-        if (le == hipSuccess) le = hipStreamWaitEvent(h->stream2, event_of(nops), 0);
-      }
-      for (size_t i = 0; i < nops && le == hipSuccess; ++i) {
-        const OpDesc& op = P->ops[i];
-        const int lane = (two_lanes && op.lane == 1) ? 1 : 0;
-        hipStream_t ls = lane ? h->stream2 : h->stream;
-        if (two_lanes)
-          for (int d : op.xdeps) {
-            le = hipStreamWaitEvent(ls, event_of((size_t)d), 0);
-            if (le != hipSuccess) break;
-          }
-        if (le == hipSuccess) le = launch_op(op, P->arena, h->packed_dev, ls);
-        if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
-      }
-      if (two_lanes && le == hipSuccess) {
-        le = hipEventRecord(event_of(nops + 1), h->stream2);
-        if (le == hipSuccess) le = hipStreamWaitEvent(h->stream, event_of(nops + 1), 0);
-      }
+      const hipError_t le = issue_lanes(h, P, h->stream);
       hipError_t ce = hipStreamEndCapture(h->stream, &P->graph);
-      if (le == hipSuccess) le = ev_err;
       if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed during capture: %s", hipGetErrorString(le));
       HIPCHK(h, ce);
       HIPCHK(h, hipGraphInstantiate(&P->graph_exec, P->graph, nullptr, nullptr, 0));
     }
     HIPCHK(h, hipGraphLaunch(P->graph_exec, s));
+  } else if (h->opt_graph == 2 && h->opt_lanes != 0) {
+    // the DEFAULT: the same two lanes and the same event edges, launched directly - lane 0 on the caller's stream, lane 1 on the
+    // handle's side stream (issue_lanes; why not a hipGraph by default: film_internal.h, opt_graph)
+    const hipError_t le = issue_lanes(h, P, s);
+    if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
   } else {
     for (const OpDesc& op : P->ops) HIPCHK(h, launch_op(op, P->arena, h->packed_dev, s));
   }

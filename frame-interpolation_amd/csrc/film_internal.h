@@ -181,7 +181,17 @@ struct film_handle {
   std::vector<std::unique_ptr<film_internal::Plan>> plans;
   film_internal::Plan* last_plan = nullptr;
   uint64_t tick = 0;
-  int opt_graph = 1, opt_profile = 0, opt_autotune = 1;
+  // How a plan is executed (option "graph"): 2 (default) = its ops are launched directly on two lanes - lane 0 on the caller's stream,
+  // lane 1 on the handle's side stream, ordered by the events of Planner::analyze_lanes; 1 = the same two lanes captured once into a
+  // hipGraph and replayed; 0 = one stream, in plan order (the reference the tests compare the other two with: bit-identical).
+  // Why the graph is not the default (round 5): the HIP runtime PyTorch 2.10+rocm7.0 bundles (7.0.51831) crashes in the FIRST
+  // hipGraphLaunch of a freshly instantiated multi-branch graph when the process has created and destroyed enough streams before -
+  // a null-ish dereference in the function that assigns the exec's parallel streams (reads past its own stream vector; backtrace and
+  // disassembly: profiles/r05_hipgraph_first_launch_crash.md).  Reproduced by the GPU test-suite in file order (8 engines, 23 graphs
+  // into the process); not reproducible in a short process.  A linear graph (lanes = 0) takes the runtime's single-stream path and
+  // is safe but serial (+2 ms per 1080p step); direct launches cost ~170 runtime calls per forward on the host, asynchronously.
+  int opt_graph = 2;
+  int opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
   int opt_fuse = 31;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)

@@ -130,7 +130,11 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
 /* Execution options.  Keys:
  *   "autotune" 0/1 time every distinct conv shape of a new plan with each fitting tile shape and keep
  *                  the fastest (default 1; cannot change results - same k-ordered fma chain per output)
- *   "graph"   0/1  replay the plan as a hipGraph (default 1)
+ *   "graph"   0/1/2  how a plan's ops reach the device.  2 (default): direct launches on two lanes - lane 0 on the caller's
+ *                  stream, lane 1 (small subtrees, coarse flow levels, the t = 0.5 warps) on a side stream of the handle, ordered by
+ *                  events; 1: the same two lanes captured once per (B, H, W) into a hipGraph and replayed; 0: one stream, plan order.
+ *                  Identical results.  The graph is opt-in since round 5: the HIP 7.0 runtime PyTorch 2.10 bundles can crash in the
+ *                  first launch of a fresh multi-branch graph late in a long-lived process (profiles/r05_hipgraph_first_launch_crash.md)
  *   "profile" 0/1  record a hipEvent pair around every kernel of the next forwards
  *                  (forces graph off); read the result with film_profile_json
  *   (options marked [extra] exist only in a library built with FILM_EXTRA_FAMILIES=1 - libfilm_hip_extra.so, see film_version();

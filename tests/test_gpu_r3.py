@@ -405,7 +405,8 @@ def test_default_plan_uses_the_nested_kernel_on_the_deep_layers_of_a_1080p_tile(
 
 
 def test_graph_replay_on_changing_inputs_at_a_1080p_tile(published):
-    """The two-lane hipGraph replay vs eager launches on the headline tile (960x576: the only size where the flow upsample is
+    """The two-lane executor (direct launches on two streams, the default; its hipGraph form: tools/graph_race_check.py in
+    test_gpu_parity.py::test_graph_replay_in_a_process_of_its_own) vs one stream in plan order on the headline tile (960x576: the only size where the flow upsample is
     its own launch on the two large levels and fused into the warps below them, and where conv_wino2d_kernel is in the default
     plan), with inputs that change every forward - a stale read in the replayed graph would show as the previous forward's
     data: image and every aligned level bit-identical; also with the decoder-on-the-side-lane op order ("lanes" = 2)."""

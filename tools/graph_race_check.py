@@ -1,4 +1,4 @@
-"""Graph replay (two lanes) vs eager launches on inputs that CHANGE every forward: any ordering / visibility hole in the
+"""Graph replay (two lanes; option "graph" = 1, or RACE_GRAPH=2 for the direct two-lane launches) vs one-stream eager launches on inputs that CHANGE every forward: any ordering / visibility hole in the
 replayed graph shows up as stale data.  Prints max|diff| per shape and forward."""
 import os, sys, numpy as np
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ from film_hip.engine import FilmEngine, hip_runtime_info
 print('HIP runtime of this process: %s  version %d = %s  (FILM_NO_TORCH=%s)' % (hip_runtime_info() + (os.environ.get('FILM_NO_TORCH', '0'),)), flush=True)
 w = W.make_synthetic_weights(PUBLISHED, seed=0)
 fuse = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-eg = FilmEngine(PUBLISHED, device=0); eg.set_weights(w); eg.set_option('fuse', fuse)
+eg = FilmEngine(PUBLISHED, device=0); eg.set_weights(w); eg.set_option('fuse', fuse); eg.set_option('graph', int(os.environ.get('RACE_GRAPH', '1')))
 ee = FilmEngine(PUBLISHED, device=0); ee.set_weights(w); ee.set_option('fuse', fuse); ee.set_option('graph', 0)
 SHAPES = ((1, 64, 64), (1, 128, 64), (2, 64, 128), (1, 256, 256), (1, 192, 320), (1, 576, 960))[:int(os.environ.get('RACE_SHAPES', '6'))]
 stale = 0
