@@ -480,7 +480,8 @@ void film_destroy(film_t* h) {
   if (!h) return;
   if (!h->plan_only) {
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    // forwards may still be running on the caller's stream and on the side lane: workspaces, events and graphs must outlive them
+    (void)hipDeviceSynchronize();
   }
   for (auto& p : h->plans) free_plan(p.get());
   if (h->packed_dev) (void)hipFree(h->packed_dev);
