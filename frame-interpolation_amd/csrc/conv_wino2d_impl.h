@@ -163,9 +163,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int ksp = p.ksplit > 1 ? p.ksplit : 1;
   const int nsc_all = p.Ctot >> 4;
   int sc0 = 0, sc1 = nsc_all;
-  if (ksp > 1) {   // (a uniform branch: an unsplit launch - every layer of the large levels - pays nothing for this in front of its first DMA
-                   // request; the first version computed the two quotients in 64 bits for every launch: 740 instead of 380
-                   // instructions between kernel entry and the first request, ~+2 % on the K <= 64 layers)
+  if (ksp > 1) {   // (a uniform branch, 32-bit quotients: 460 instead of 740 instructions between kernel entry and the first DMA request of
+                   // an unsplit launch - round 4's kernel had 380.  Same-box A/B on the K <= 64 ... 528 layer shapes: no measurable
+                   // difference, the scalar work hides behind the other waves' - profiles/r05_w2d_prologue_fix.log)
     sc0 = (int)((unsigned)nsc_all * blockIdx.z / (unsigned)ksp);            // nsc_all * ksplit < 2^16 * 2^4
     sc1 = (int)((unsigned)nsc_all * (blockIdx.z + 1u) / (unsigned)ksp);
     int c = sc0 * 16;   // the DMA cursor starts at this split's first super-chunk: walk the concat segments
