@@ -7,7 +7,7 @@ O=$R/gpurun_out/r05f
 mkdir -p $O
 cd $R
 t0=$(date +%s); lap() { t1=$(date +%s); echo "[$1: $((t1-t0)) s]"; t0=$t1; }
-# same-box A/B of the split-K index math in front of the first DMA request (tools/bin/w2d_bench_before = the kernel of commit 6c1e3d9's parent tree)
+# same-box A/B of the split-K index math in front of the first DMA request (tools/bin/w2d_bench_before = the kernel of commit e9480fd)
 if [ -x tools/bin/w2d_bench_before ]; then
   for sh in 15 10 18 7 16 6 0 1; do for which in w2d_bench_before w2d_bench w2d_bench_before w2d_bench; do echo "## $which"; timeout 60 tools/bin/$which 10 $sh "=w2d 64,=w2d 32"; done; done > $O/r05_w2d_prologue_fix.log 2>&1
   grep -E "^##|^==|w2d (64|32) " $O/r05_w2d_prologue_fix.log | cut -c1-120 | head -100; lap w2d_ab
