@@ -295,6 +295,23 @@ def test_invalid_options_rejected():
         Options(filters=20).validate()
 
 
+def test_executor_option_is_three_valued():
+    """Option "graph" (include/film_hip.h): 0 = one stream, 1 = hipGraph replay, 2 = direct two-lane launches (the default since
+    round 5); anything else is refused with a message.  The plan itself (ops, lanes, cross-lane edges) does not depend on it."""
+    from film_hip.engine import FilmEngine, FilmError
+    from film_hip.options import TINY
+    eng = FilmEngine(TINY, device=-1)
+    base = eng.plan(1, 64, 64)
+    for v in (0, 1, 2):
+        eng.set_option('graph', v)
+        assert eng.plan(1, 64, 64) == base
+    for v in (-1, 3):
+        with pytest.raises(FilmError, match='graph'):
+            eng.set_option('graph', v)
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'film_hip.h')).read()
+    assert '"graph"   0/1/2' in header and '2 (default)' in header
+
+
 def test_lane_analysis_orders_every_conflict(tiny_weights):
     """Two-stream replay: for every pair of ops on different lanes that touch overlapping channels of one buffer
     (RAW / WAR / WAW) the later one must be ordered behind the earlier one through the xdeps edges + per-lane
