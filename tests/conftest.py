@@ -29,6 +29,18 @@ _keep_large_allocations_in_the_heap()
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu via gpurun)')
+    # FILM_TEST_EXECUTOR=0|1|2: every engine a test creates starts with that value of option "graph" (1 = the hipGraph replay that was
+    # the default until round 5) - for re-running the suite on another executor, e.g. to reproduce profiles/r05_hipgraph_first_launch_crash.md
+    forced = os.environ.get('FILM_TEST_EXECUTOR')
+    if forced:
+        from film_hip.engine import FilmEngine
+        orig = FilmEngine.__init__
+
+        def init(self, *a, **k):
+            orig(self, *a, **k)
+            if self.device >= 0:
+                self.set_option('graph', int(forced))
+        FilmEngine.__init__ = init
 
 
 def has_extra_families() -> bool:
