@@ -153,7 +153,7 @@ class FilmEngine:
         cfg = _cfg_struct(opt)
         rc = self._lib.film_create(ctypes.byref(self._h), device, ctypes.byref(cfg))
         if rc != 0:
-            msg = self._lib.film_last_error(None).decode()
+            msg = self._lib.film_last_error(None).decode('utf-8', 'replace')
             self._h = ctypes.c_void_p()
             raise FilmError(rc, msg)
         self.device = device
@@ -172,7 +172,7 @@ class FilmEngine:
 
     def _check(self, rc: int) -> None:
         if rc != 0:
-            raise FilmError(rc, self._lib.film_last_error(self._h).decode())
+            raise FilmError(rc, self._lib.film_last_error(self._h).decode('utf-8', 'replace'))
 
     @property
     def options(self) -> Options:
@@ -197,9 +197,11 @@ class FilmEngine:
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self._lib.film_load_bundle(self._h, os.fsencode(path), 1 if verify else 0, buf, len(buf), ctypes.byref(need)))
         rep = {}
-        for line in buf.value.decode().splitlines():
-            name, rule, key = line.split('\t')
-            rep[name] = (rule, key)
+        # (checkpoint keys are bytes of the file: with verify=False a damaged index can hand back anything)
+        for line in buf.value.decode('utf-8', 'replace').splitlines():
+            parts = line.split('\t')
+            if len(parts) == 3:
+                rep[parts[0]] = (parts[1], parts[2])
         by_shape = sorted(n for n, (rule, _) in rep.items() if rule != 'path')
         if by_shape:
             import logging

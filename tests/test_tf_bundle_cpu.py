@@ -311,3 +311,55 @@ def test_interpolator_takes_the_native_path_for_a_savedmodel_directory(tmp_path,
     ref = _native(TINY)
     ref.set_weights(tiny_weights)
     assert np.array_equal(it.engine.export_packed(), ref.export_packed())
+
+
+@pytest.mark.parametrize('verify', [True, False])
+def test_native_loader_survives_damaged_bundles(tmp_path, tiny_weights, verify):
+    """A SavedModel directory is a file from somewhere else: 120 seeded mutations (flipped bytes, truncations, 0xff runs, insertions;
+    mostly in the index table) of the two writers' bundles must end in FILM_OK or in a FilmError with a message - never in another
+    exception (the checkpoint keys in reports and messages are bytes of the file) and never in a crash.  With verify=False the crc
+    checks that catch most of them are off and the table / proto parsers see the damage themselves.  (A longer run of the same
+    mutator, 9 000 cases, found two UnicodeDecodeErrors in film_hip/engine.py and nothing in csrc/film_bundle.cpp.)"""
+    import random
+    import shutil
+    import tf_like_writer as tw
+    from film_hip import tf_bundle as tb
+    from film_hip.engine import FilmError
+    from film_hip.options import TINY
+    bw.save_film_bundle(str(tmp_path / 'a'), tiny_weights, TINY)
+    full = {tb.checkpoint_key(n, TINY)[:-len(tb.VAR_SUFFIX)]: n for n in tiny_weights}
+    tw.write_tf_like_bundle(str(tmp_path / 'b' / 'variables' / 'variables'), _paths(tiny_weights, TINY), full_names=full, num_shards=2, block_size=384)
+    rng = random.Random(5 + int(verify))
+    loaded = refused = 0
+    for case in range(120):
+        dst = tmp_path / 'case'
+        shutil.rmtree(dst, ignore_errors=True)
+        shutil.copytree(tmp_path / ('a' if rng.random() < 0.5 else 'b'), dst)
+        files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(dst) for f in fs)
+        idx = [f for f in files if f.endswith('.index')]
+        f = rng.choice(idx) if rng.random() < 0.8 else rng.choice(files)
+        b = bytearray(open(f, 'rb').read())
+        mode = rng.random()
+        if mode < 0.5:
+            for _ in range(rng.choice([1, 1, 2, 4, 8])):
+                b[rng.randrange(len(b))] = rng.randrange(256)
+        elif mode < 0.7:
+            b = b[:rng.randrange(len(b))]
+        elif mode < 0.85:
+            p = rng.randrange(len(b))
+            b[p:p + rng.choice([1, 4, 8])] = bytes([0xff] * rng.choice([1, 4, 8]))
+        else:
+            p = rng.randrange(len(b))
+            b[p:p] = bytes(rng.randrange(256) for _ in range(rng.choice([1, 3, 16])))
+        with open(f, 'wb') as fh:
+            fh.write(bytes(b))
+        eng = _native(TINY)
+        try:
+            eng.load_bundle(str(dst), verify=verify)
+            loaded += 1
+        except FilmError as e:
+            assert e.msg
+            refused += 1
+        finally:
+            eng.close()
+    assert loaded + refused == 120 and refused > (100 if verify else 40)
