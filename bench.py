@@ -113,7 +113,7 @@ def parity_check(workload, fn, dev):
     d = G.diff(g, 'image', got.cpu().numpy())
     return got.clone(), {'max_abs_vs_ref_graph_golden' if prov != 'tf' else 'max_abs_vs_tensorflow_golden': d,
                          'golden': f'tests/golden/{"tf" if prov == "tf" else "ref"}_{case}.npz', 'tolerance': PARITY_TOL,
-                         'through': 'the timed callable itself (DeviceInterpolator, same engine handle / graph / lanes), device-resident frames'}
+                         'through': 'the timed callable itself (DeviceInterpolator, same engine handle / executor / lanes), device-resident frames'}
 
 
 def synth_pair(h, w, seed):
@@ -363,8 +363,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='one stream, plan order (option graph = 0)')
     ap.add_argument('--graph', action='store_true', help='hipGraph replay of the two lanes (option graph = 1) instead of the default direct two-lane launches')
     ap.add_argument('--lanes', type=int, default=1, choices=[0, 1, 2],
-                    help='0: replay the graph on ONE stream (serialised kernels: what the committed rocprofv3 kernel trace uses, '
-                         'so that per-kernel durations are not inflated by overlap); 1: two-stream graph, decoder behind the flow '
+                    help='0: every op on ONE stream (serialised kernels: what the committed rocprofv3 kernel trace uses, '
+                         'so that per-kernel durations are not inflated by overlap); 1: two lanes (side stream for the small / HBM-bound work), decoder behind the flow '
                          'estimator (default); 2: coarse decoder levels on the side stream beside the estimator (measured slower)')
     ap.add_argument('--precision', type=int, default=0, choices=[0, 1, 2],
                     help='engine precision mode of the MAIN measurement: 0 = fp32 MFMA (default, the headline), 1 = bf16x6, 2 = bf16x3')
@@ -524,7 +524,7 @@ def main():
         reported = int(ones.item())
     assert (out is not None or (strong and rank != 0)) and (out is None or bool(torch.isfinite(out).all()))
     # the timed output itself: the last timed step must reproduce the first call on the same inputs bit for bit (no atomics,
-    # fixed summation orders: a replayed graph that read stale data would show here), and the golden pair pushed through the
+    # fixed summation orders: a side lane or a replayed graph that read stale data would show here), and the golden pair pushed through the
     # timed callable AFTER the loop must reproduce its pre-loop result bit for bit
     timed_same = None if (out is None or first is None) else bool(torch.equal(out, first))
     if parity is not None:
@@ -558,7 +558,7 @@ def main():
                 frames = nxt
             del frames, mids, nxt
         # ---- roofline of the dominant kernel class: hipEvents around every launch, on the launch stream
-        # steady state: a normal (graph) forward is queued right in front of the profiled one, with no host
+        # steady state: a normal forward is queued right in front of the profiled one, with no host
         # synchronisation in between, so the first kernels are not timed on a GPU that is ramping up from idle
         it(x0, x1)
         eng.set_option('profile', 1)
