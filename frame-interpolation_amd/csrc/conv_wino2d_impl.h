@@ -53,7 +53,8 @@ enum { W2D_F_XFIRST = 32,      // tools only: x transform per row, then the y co
        W2D_DBG_NOBAR = 2048,   // no barrier in the K loop
        W2D_DBG_NORD = 4096,    // no fragment reads in the K loop
        W2D_DBG_TIME = 8192 };  // wave 0 of every workgroup writes s_memtime at kernel entry / first MFMA / last MFMA / exit to
-                               // p.part[workgroup * 8 ..], and behind the first DMA request / its own stage-0 share / the first barrier
+                               // p.part[workgroup * 16 ..], behind the first DMA request / its own stage-0 share / the first barrier, and the
+                               // cycles it spent in the K loop's s_waitcnt + barrier pairs (slot 7)
                                // (tools/w2d_bench.hip prints the averages)
 
 // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): the MFMA gaps of a chunk, every index a compile-time constant
@@ -84,8 +85,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int l31 = lane & 31, half = lane >> 5;
   const int mu = wv & 3, ng = wv >> 2;
 
-  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tmA = 0, tmB = 0, tmC = 0;
-  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm0 = __builtin_readcyclecounter();
+  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tmA = 0, tmB = 0, tmC = 0, tmW = 0;
+  unsigned long long rt0 = 0;
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { rt0 = __builtin_amdgcn_s_memrealtime(); tm0 = __builtin_readcyclecounter(); }
 
   int bx = blockIdx.x, by = blockIdx.y;
   if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
@@ -319,12 +321,15 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       // This wave's requests for super-chunk s + 1 are older than the weight requests of the last chunks (in-order return): the last
       // one went out in a gap of chunk kc - 3, at least 14 weight requests ago (s + 1 < 3: in the prologue, behind it DMA requests
       // and the 6 weight requests of chunk 0).  Everybody else's are published by the barrier.
+      unsigned long long tw0 = 0;
+      if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tw0 = __builtin_readcyclecounter();
       if constexpr ((FLAGS & W2D_DBG_NOB) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else {
         if (kc == kc0 + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       }
       if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
+      if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmW += __builtin_readcyclecounter() - tw0;   // s_waitcnt + barrier of this super-chunk
       dma_on = (kc >> 1) + NS < sc1;
       st_dma = st_s;
     }
@@ -529,8 +534,12 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) {
     const unsigned long long tm3 = __builtin_readcyclecounter();
     if (t == 0) {
-      unsigned long long* o8 = reinterpret_cast<unsigned long long*>(p.part) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8;
-      o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3; o8[4] = tmA; o8[5] = tmB; o8[6] = tmC;
+      // 16 slots per workgroup; 8 / 9: the 100 MHz wall clock at entry / exit (s_memtime counts shader cycles, per CU group: only stamps of
+      // one CU compare); 10: HW_ID (bits 8..15: CU, SH, SE) | XCC_ID << 32 - which CU ran this workgroup
+      unsigned long long* o8 = reinterpret_cast<unsigned long long*>(p.part) + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 16;
+      o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3; o8[4] = tmA; o8[5] = tmB; o8[6] = tmC; o8[7] = tmW;
+      o8[8] = rt0; o8[9] = __builtin_amdgcn_s_memrealtime();
+      o8[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
     }
   }
 }

@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -183,6 +184,9 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 3;
   const int only_shape = argc > 2 ? atoi(argv[2]) : -1;      // -1: all shapes
   const char* only_variant = argc > 3 ? argv[3] : nullptr;   // substring filter on the variant name
+  // tools/bin/w2d_bench reps -2 variants NB H W C Cout: ONE shape from the command line (every 3x3 layer of a plan: tools/w2d_idle_budget.py)
+  std::vector<Shape> shape_list(std::begin(shapes), std::end(shapes));
+  if (only_shape == -2 && argc > 8) { shape_list.assign(1, Shape{"custom", atoi(argv[4]), atoi(argv[5]), atoi(argv[6]), atoi(argv[7]), atoi(argv[8]), 0}); }
   hipStream_t st;
   CK(hipStreamCreate(&st));
   hipEvent_t e0, e1;
@@ -191,7 +195,7 @@ int main(int argc, char** argv) {
   double* d_sum;
   CK(hipMalloc(&d_sum, sizeof(double)));
   int shape_idx = -1, bad = 0;
-  for (const Shape& sh : shapes) {
+  for (const Shape& sh : shape_list) {
     if (++shape_idx != only_shape && only_shape >= 0) continue;
     const size_t M = (size_t)sh.NB * sh.H * sh.W;
     const int C1 = sh.C - sh.C2;
@@ -218,7 +222,7 @@ int main(int argc, char** argv) {
     CK(hipStreamSynchronize(st));
     unsigned long long* d_tm;
     const size_t n_tm = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / 32) * 8;
-    CK(hipMalloc(&d_tm, n_tm * 8 + 16384));
+    CK(hipMalloc(&d_tm, n_tm * 16 + 16384));
     CK(hipMemset(d_tm, 0, 16384));
     ConvParams p{};
     p.part = reinterpret_cast<float*>(d_tm);
@@ -285,18 +289,38 @@ int main(int argc, char** argv) {
       }
       if (strstr(v.name, "time")) {   // per-workgroup phase times (shader clock ticks = 100 MHz s_memtime? printed raw) and the per-CU timeline
         const size_t nwg = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / v.bn);
-        std::vector<unsigned long long> tm(nwg * 8);
-        CK(hipMemcpy(tm.data(), d_tm, nwg * 64, hipMemcpyDeviceToHost));
-        double pro = 0, loop = 0, epi = 0, pa = 0, pb = 0, pc = 0;
-        unsigned long long tmin = ~0ull, tmax = 0;
+        std::vector<unsigned long long> tm(nwg * 16);
+        CK(hipMemcpy(tm.data(), d_tm, nwg * 128, hipMemcpyDeviceToHost));
+        double pro = 0, loop = 0, epi = 0, pa = 0, pb = 0, pc = 0, wait = 0, life = 0, cyc = 0, rt = 0;
+        // s_memtime counts shader cycles on a counter of the workgroup's own CU group: stamps compare within one CU only.  Per CU (HW_ID bits
+        // 8..15 + XCC_ID): its span (first entry .. last exit), the summed lifetimes of its workgroups, how many it ran.
+        struct CuAcc { unsigned long long t0 = ~0ull, t1 = 0; double busy = 0; int n = 0; };
+        std::map<unsigned long long, CuAcc> cus;
         for (size_t i = 0; i < nwg; ++i) {
-          pa += (double)(tm[i * 8 + 4] - tm[i * 8]); pb += (double)(tm[i * 8 + 5] - tm[i * 8 + 4]); pc += (double)(tm[i * 8 + 6] - tm[i * 8 + 5]);
-          pro += (double)(tm[i * 8 + 1] - tm[i * 8]); loop += (double)(tm[i * 8 + 2] - tm[i * 8 + 1]); epi += (double)(tm[i * 8 + 3] - tm[i * 8 + 2]);
-          if (tm[i * 8] < tmin) tmin = tm[i * 8];
-          if (tm[i * 8 + 3] > tmax) tmax = tm[i * 8 + 3];
+          const unsigned long long* e = &tm[i * 16];
+          pa += (double)(e[4] - e[0]); pb += (double)(e[5] - e[4]); pc += (double)(e[6] - e[5]);
+          pro += (double)(e[1] - e[0]); loop += (double)(e[2] - e[1]); epi += (double)(e[3] - e[2]);
+          wait += (double)e[7]; life += (double)(e[3] - e[0]);
+          cyc += (double)(e[3] - e[0]); rt += (double)(e[9] - e[8]);
+          CuAcc& c = cus[(e[10] & 0xFF00ull) | (e[10] >> 32 << 16)];
+          if (e[0] < c.t0) c.t0 = e[0];
+          if (e[3] > c.t1) c.t1 = e[3];
+          c.busy += (double)(e[3] - e[0]); ++c.n;
         }
-        printf("   [time] %zu workgroups: prologue %.0f (entry -> first DMA issued %.0f, -> stage 0 landed %.0f, -> barrier passed %.0f, -> fragments of chunk 0 ready)  K loop %.0f  epilogue %.0f cycles (averages); kernel span %llu\n", nwg,
-               pro / nwg, pa / nwg, pb / nwg, pc / nwg, loop / nwg, epi / nwg, tmax - tmin);
+        double span_max = 0, span_avg = 0, busy_avg = 0; int n_min = 1 << 30, n_max = 0;
+        for (auto& kv : cus) {
+          const double sp = (double)(kv.second.t1 - kv.second.t0);
+          span_max = sp > span_max ? sp : span_max; span_avg += sp / cus.size(); busy_avg += kv.second.busy / cus.size();
+          n_min = kv.second.n < n_min ? kv.second.n : n_min; n_max = kv.second.n > n_max ? kv.second.n : n_max;
+        }
+        const double ghz = rt > 0 ? cyc / rt * 0.1 : 0;   // shader cycles per 10 ns tick of s_memrealtime
+        printf("   [time] %zu workgroups on %zu CUs (%d..%d each): prologue %.0f (entry -> first DMA issued %.0f, -> stage 0 landed %.0f, -> barrier passed %.0f, -> fragments of chunk 0 ready)  K loop %.0f (of it s_waitcnt + barrier %.0f)  epilogue %.0f cycles (averages); span per CU max %.0f avg %.0f cycles, clock %.3f GHz\n", nwg, cus.size(), n_min, n_max,
+               pro / nwg, pa / nwg, pb / nwg, pc / nwg, loop / nwg, wait / nwg, epi / nwg, span_max, span_avg, ghz);
+        // one machine-readable line per timed launch (tools/w2d_idle_budget.py): per-workgroup averages in shader cycles, per-CU span / summed
+        // workgroup lifetimes, the clock, and the event time of this variant's fastest repetition
+        printf("   [time-json] {\"shape\": \"%s\", \"NB\": %d, \"H\": %d, \"W\": %d, \"C\": %d, \"Cout\": %d, \"bn\": %d, \"nwg\": %zu, \"prologue\": %.1f, \"loop\": %.1f, \"wait\": %.1f, "
+               "\"epilogue\": %.1f, \"life\": %.1f, \"ncu\": %zu, \"span_max\": %.0f, \"span_avg\": %.0f, \"cu_busy_avg\": %.0f, \"wg_per_cu_min\": %d, \"wg_per_cu_max\": %d, \"ghz\": %.4f, \"ms\": %.5f}\n",
+               sh.name, sh.NB, sh.H, sh.W, sh.C, sh.Cout, v.bn, nwg, pro / nwg, loop / nwg, wait / nwg, epi / nwg, life / nwg, cus.size(), span_max, span_avg, busy_avg, n_min, n_max, ghz, best);
         // busy share of one CU slot: follow the workgroups that ran on the CU of workgroup 0 (same hw_id CU/SE bits and XCC)
       }
       const bool abl = v.fam < 0;
