@@ -579,7 +579,7 @@ def main():
         # FLOPs the matrix pipe really executes: the Winograd F(2,3) kernel (tile id & 256) does 2/3 of the direct
         # convolution's multiplies, the sub-pixel-folded upsample + 2x2 conv (tag ':phases') 9/16
         exec_flops = 0.0
-        per_kernel = {k: {'launches': 0, 'ms': 0.0, 'executed_flops': 0.0} for k in ('conv_wino2d_kernel', 'conv_wino43_kernel')}
+        per_kernel = {k: {'launches': 0, 'ms': 0.0, 'executed_flops': 0.0} for k in ('conv_wino2d_kernel', 'conv_wino43_kernel', 'conv_fold4_kernel')}
         for o in prof['ops']:
             if o['kind'] != 'conv_mfma':
                 continue
@@ -588,10 +588,12 @@ def main():
                 f *= 1.0 / 3.0                                   # nested Winograd F(4,3)x x F(2,3)y: 3 multiplies per output of 9
             elif o['tile'] & 256:
                 f *= 0.5 if o['tile'] & 2048 else 2.0 / 3.0    # Winograd F(4,3) / F(2,3) along x
+            elif o['tile'] & 16384:
+                f *= 4.0 / 16.0                                  # conv_fold4_kernel: upsample + 2x2 in its difference form, 4 multiplies of 16
             elif o['tag'].endswith(':phases'):
                 f *= 9.0 / 16.0
             exec_flops += f
-            kname = 'conv_wino2d_kernel' if (o['tile'] & 8192) else 'conv_wino43_kernel' if ((o['tile'] & 256) and (o['tile'] & 2048)) else None
+            kname = 'conv_wino2d_kernel' if (o['tile'] & 8192) else 'conv_fold4_kernel' if (o['tile'] & 16384) else 'conv_wino43_kernel' if ((o['tile'] & 256) and (o['tile'] & 2048)) else None
             if kname:
                 per_kernel[kname]['launches'] += 1
                 per_kernel[kname]['ms'] += o['ms']
@@ -641,7 +643,7 @@ def main():
                 {'name': k, 'launches': v['launches'], 'ms': round(v['ms'], 3),
                  'executed_tflops': round(v['executed_flops'] / max(v['ms'], 1e-9) / 1e9, 3),
                  'frac': round(v['executed_flops'] / max(v['ms'], 1e-9) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
-                 'direct_equivalent_tflops': round(v['executed_flops'] * (3.0 if k == 'conv_wino2d_kernel' else 2.0) / max(v['ms'], 1e-9) / 1e9, 3),
+                 'direct_equivalent_tflops': round(v['executed_flops'] * (3.0 if k == 'conv_wino2d_kernel' else 4.0 if k == 'conv_fold4_kernel' else 2.0) / max(v['ms'], 1e-9) / 1e9, 3),
                  'avg_launch_ms': round(v['ms'] / max(1, v['launches']), 5)}
                 for k, v in sorted(per_kernel.items(), key=lambda kv: -kv[1]['ms']) if v['launches']],
             'launches_per_step': conv['launches'],

@@ -20,15 +20,18 @@
 //   conv_buf_impl.h    the general kernel (1x1, small levels, and the sub-pixel-folded upsample + 2x2 convs): buffer
 //                      loads with hardware zero fill, K-major weights, no vector instruction per K-step besides loads,
 //                      LDS traffic and MFMAs.
+//   conv_fold4_impl.h  the decoder's nearest x2 upsample + 2x2 conv in its difference form: 4 multiplies per low-resolution pixel
+//                      instead of the 9 of the sub-pixel fold on conv_buf_kernel.
 //   conv_c3_impl.h     the 3-channel first layer (K = 27): no LDS, weights in registers.
 // (conv_igemm_impl.h, the first-generation kernel that ran the first layer of configurations with filters other than 32 / 64 until
 // round 4, is under tools/retired/.)
-// The default library instantiates only the families a default plan can select: conv_wino2d / conv_wino43 / conv_buf / conv_c3.
+// The default library instantiates only the families a default plan can select: conv_wino2d / conv_wino43 / conv_fold4 / conv_buf / conv_c3.
 // FILM_EXTRA_FAMILIES=1 at build time (film_hip/build.py, Makefile EXTRA=1) adds the ones behind opt-in options: the bf16 split
 // precision modes (conv_split / conv_winox3 / conv_foldx3) and the F(2,3) / halo fp32 kernels (options winograd = 2, halo_all).
 #include "conv_buf_impl.h"
 #include "conv_wino43_impl.h"
 #include "conv_wino2d_impl.h"
+#include "conv_fold4_impl.h"
 #include "conv_c3_impl.h"
 #ifdef FILM_EXTRA_FAMILIES
 #include "conv_halo_impl.h"
@@ -135,6 +138,15 @@ static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
   }
 }
 
+template <int F>
+static hipError_t launch_fold4(const ConvParams& p, int shape, hipStream_t s) {
+  switch (shape) {
+    case F4_4x64: return conv_fold4_launch<2, F>(p, s);
+    case F4_4x32: return conv_fold4_launch<1, F>(p, s);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 #ifdef FILM_EXTRA_FAMILIES
 template <int F>
 static hipError_t launch_winox3(const ConvParams& p, int shape, hipStream_t s) {
@@ -185,6 +197,7 @@ __global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __
 static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream_t s) {
   const int shape = (tile & (CONV_TILE_XCD - 1)) + (((tile & CONV_TILE_EXT) && (tile & CONV_TILE_F43)) ? 16 : 0);
   if ((p.pool_out != nullptr || p.pw_out != nullptr) && !(tile & CONV_TILE_W2D) && !((tile & CONV_TILE_WINO) && (tile & CONV_TILE_F43) && !(tile & CONV_TILE_X3))) return hipErrorInvalidValue;
+  if (tile & CONV_TILE_FOLD4) return (tile & CONV_TILE_XCD) ? launch_fold4<CONV_B_XCD_M>(p, shape, s) : launch_fold4<0>(p, shape, s);   // (the launcher checks the op)
   if (tile & CONV_TILE_W2D) {
     if (p.ksize != 3) return hipErrorInvalidValue;   // (fused pool / 1x1: checked by the launcher)
     return (tile & CONV_TILE_XCD) ? launch_wino2d<CONV_B_XCD_M>(p, shape, s) : launch_wino2d<0>(p, shape, s);
@@ -232,7 +245,7 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
   // split-K is implemented by conv_buf_kernel, conv_wino43_kernel and conv_wino2d_kernel
-  const bool can_split = !(tile & (CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
+  const bool can_split = !(tile & (CONV_TILE_FOLD4 | CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
                          (!(tile & CONV_TILE_WINO) || (tile & CONV_TILE_F43));
   if (p.ksplit > 1 && !can_split) return hipErrorInvalidValue;
   const hipError_t e = film_launch_conv_main(p, tile, s);

@@ -170,6 +170,12 @@ std::vector<int> wino2d_candidates(int Cout, bool pw = false) {
   return out;
 }
 
+std::vector<int> fold4_candidates(int Cout) {
+  std::vector<int> out;
+  for (int sh : (Cout % 64 == 0 ? std::vector<int>{F4_4x64, F4_4x32} : std::vector<int>{F4_4x32})) { out.push_back(sh | CONV_TILE_FOLD4); out.push_back(sh | CONV_TILE_FOLD4 | CONV_TILE_XCD); }
+  return out;
+}
+
 std::vector<int> foldx3_candidates(int Cout) {
   std::vector<int> shapes = Cout % 128 == 0 ? std::vector<int>{FX3_4x64, FX3_8x64, FX3_4x128} : std::vector<int>{FX3_4x64, FX3_8x64};
   std::vector<int> out;
@@ -216,7 +222,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
-  std::vector<int> cands = (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, op.pw_out.buf >= 0) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  std::vector<int> cands = op.fold == 3 ? fold4_candidates(op.Cout) : (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, op.pw_out.buf >= 0) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
   if (op.c3) {   // the 3-channel first layer has one kernel (conv_c3_kernel)
     cands.clear();
     cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
@@ -397,6 +403,13 @@ int get_plan(film_t* h, int B, int H, int W, bool need_device, Plan** out) {
       const int want = h->opt_w2d_shape | CONV_TILE_W2D | CONV_TILE_XCD;
       if (std::find(cands.begin(), cands.end(), want) != cands.end()) op.tile = want;
     }
+  if (h->opt_fold4_shape >= 0)   // ... and for conv_fold4_kernel's
+    for (OpDesc& op : P->ops) {
+      if (op.kind != OP_CONV || op.fold != 3) continue;
+      const std::vector<int> cands = conv_candidates(op);
+      const int want = h->opt_fold4_shape | CONV_TILE_FOLD4 | CONV_TILE_XCD;
+      if (std::find(cands.begin(), cands.end(), want) != cands.end()) op.tile = want;
+    }
   P->last_use = ++h->tick;
   *out = P.get();
   h->plans.push_back(std::move(P));
@@ -526,12 +539,15 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "fold2x2")) {
-    if ((value != 0) != (h->opt_fold != 0)) {  // plans carry the op list: drop them
+    if (value < 0 || value > 2) return fail(h, FILM_ERR_INVALID, "fold2x2: 0, 1 or 2");
+    const int fold = value != 0, fold4 = value == 1;
+    if (fold != h->opt_fold || fold4 != h->opt_fold4) {  // plans carry the op list: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
       h->plans.clear();
       h->last_plan = nullptr;
-      h->opt_fold = value != 0;
+      h->opt_fold = fold;
+      h->opt_fold4 = fold4;
     }
   }
   else if (!strcmp(key, "planar")) {
@@ -615,6 +631,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->plans.clear();
       h->last_plan = nullptr;
       h->opt_w2d_shape = (int)value;
+    }
+  }
+  else if (!strcmp(key, "fold4_shape")) {
+    if (value < -1 || value > F4_4x32) return fail(h, FILM_ERR_INVALID, "fold4_shape: -1 (autotuned) or a Fold4Tile shape index");
+    if ((int)value != h->opt_fold4_shape) {  // plans carry the tile choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_fold4_shape = (int)value;
     }
   }
   else if (!strcmp(key, "w43_shape")) {

@@ -80,6 +80,7 @@ struct OpDesc {
   int64_t w43_off = -1;               // conv: the layer's Winograd F(4,3) weight copy (conv_wino43_kernel)
   int64_t w2d_off = -1;               // conv: the layer's nested F(4,3) x F(2,3) weight copy (conv_wino2d_kernel; deep-K layers only)
   int64_t wfx_off = -1;               // conv: phase-summed weights of a folded 2x2 layer as bf16 hi / mid (conv_foldx3_kernel)
+  int64_t wf4_off = -1;               // conv: the difference-form planes S, Sx, Sy, W11 of a folded 2x2 layer (conv_fold4_kernel; = w_off when fold == 3)
   int wino = 0;                       // conv: 1 = runs on conv_wino_kernel, 2 = on conv_winox3_kernel (precision bf16x3), 3 = conv_wino43_kernel,
                                       //       4 = conv_wino2d_kernel (nested F(4,3) x F(2,3))
   int split = 0;                      // conv: runs on conv_halo_split_kernel (precision mode bf16x6)
@@ -118,6 +119,8 @@ struct LayerPack {
   int64_t ww_off = -1;       // ... the F(2,3)-along-x transformed copy for conv_wino_kernel, [Cout][ctot/8][12][8]
   int64_t wfx_off = -1;      // 2x2 layers after an upsample: the phase-summed weights as bf16 hi / mid for conv_foldx3_kernel,
                              //     [Cout][ctot/16][9 (tap, phase) steps][plane][16] bf16
+  int64_t wf4_off = -1;      // 2x2 layers behind a nearest upsample: the four planes of the difference form (conv_fold4_impl.h) S = ((W00 + W01) + W10) +
+                             //     W11, Sx = W01 + W11, Sy = W10 + W11, W11 as [Cout/32][ctot/8][plane 4][K half][32][4]: 4*ctot*cout in all
   int64_t w43_off = -1;      // ... the F(4,3)-along-x transformed copy for conv_wino43_kernel, [Cout][ctot/8][3 dy][6 nu][8]
   int64_t w2d_off = -1;      // has_w2d layers: the nested F(4,3)x x F(2,3)y copy for conv_wino2d_kernel,
                              //     [Cout/32][ctot/8][mu 4][nu 6][K half][32][4] (24 values per (ci, co): 2.67x the kernel)
@@ -197,6 +200,7 @@ struct film_handle {
   int opt_fuse = 31;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_planar = 1;     // 1: aligned-pyramid levels as three planes (feat0 | feat1 | misc16), each written contiguously by its warp
   int opt_fold = 1;       // 1: nearest-upsample + 2x2 conv as four sub-pixel phase convolutions (9 taps per 4 outputs)
+  int opt_fold4 = 1;      // (with opt_fold) 1: ... in the difference form on conv_fold4_kernel (4 multiplies per low-resolution pixel instead of 9)
   int opt_wino = 1;       // 0: never, 1: Winograd kernels (F(4,3) / F(2,3)) where measured faster (default), 2 / 3: F(2,3) / F(4,3) on every eligible 3x3 conv
   int opt_halo_all = 0;   // 1: halo / split kernels for every eligible 3x3 conv regardless of size (tests, tuning)
   int opt_tune_ms = 0;    // autotune: minimum kernel time spent per candidate (0: two launches)
@@ -211,6 +215,7 @@ struct film_handle {
                              // profiles/r04_w2d_min_px_ab.log: 8 or more 8x32 patches per image - 32x56 yes, 32x32 no)
   int opt_w2d_splitk = 1; // 1: split-K for the nested kernel's deep-K layers on levels of <= 16 384 pixels (planner rule; option "w2d_splitk" for A/B runs)
   int opt_w2d_shape = -1; // tests: >= 0 = every conv_wino2d_kernel op that can run this Wino2dTile shape does
+  int opt_fold4_shape = -1; // tests: >= 0 = every conv_fold4_kernel op that can run this Fold4Tile shape does
   int opt_w43_shape = -1; // tests: >= 0 = every conv_wino43_kernel op that can run this Wino43Tile shape does (instead of the autotuned one)
   std::string profile_json;
   std::map<std::string, int> tune_cache;  // conv shape signature -> fastest tile

@@ -46,6 +46,9 @@ struct ConvParams {
   // weights [Cout][ftaps * Ctot] pre-summed over the kernel taps that read the same input pixel.
   // fold = 2: all four phases in ONE launch, phase = blockIdx.z = py*2 + px, taps (a, b) with a <= py, b <= px in
   // raster order, weights of phase q at w + fold_woff[q] (py, px, ftaps, tdy, tdx are then ignored).
+  // fold = 3 (conv_fold4_kernel, conv_fold4_impl.h): the same op in its difference form - four GEMMs over K = Ctot on the planes
+  // I, Dx, Dy, Dxy of the low-resolution input, combined in the epilogue; weights [Cout/32][chunk of 8][plane 4][K half][32][4]
+  // (S, Sx, Sy, W11); py, px, ftaps, tdy, tdx, fold_woff are ignored.
   int fold, py, px, ftaps;
   signed char tdy[4], tdx[4];
   long long fold_woff[4];
@@ -205,6 +208,8 @@ enum ConvTile { TILE_128x128 = 0, TILE_256x64 = 1, TILE_256x32 = 2, TILE_64x64 =
                 CONV_TILE_W2D = 8192 /* conv_wino2d_kernel (nested F(4,3)x x F(2,3)y, fp32): shape index = Wino2dTile, weights
                                         [Cout/32][chunk of 8][mu 4][nu 6][K half][32][4] */,
                 CONV_TILE_EXT = 4096 /* conv_wino43_kernel: shape index = (tile & 15) + 16 */,
+                CONV_TILE_FOLD4 = 16384 /* conv_fold4_kernel (nearest x2 upsample + 2x2 conv in its difference form, fp32): shape index =
+                                           Fold4Tile, weights [Cout/32][chunk of 8][plane 4][K half][32][4] */,
                 CONV_TILE_FOLDX3 = 1024 /* conv_foldx3_kernel (precision mode bf16x3, folded upsample + 2x2): shape index =
                                            FoldX3Tile, weights [Cout][chunk][9 (tap, phase) steps][plane][16] bf16 */ };
 // conv_wino43_kernel tiles (CONV_TILE_WINO | CONV_TILE_F43): patch rows x 128 pixels x output channels, wave block TM x TN
@@ -227,6 +232,9 @@ enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_
 // conv_wino2d_kernel tiles (CONV_TILE_W2D): one 32-unit MFMA tile (unit = 2 rows x 4 pixels; 8 rows x 32 pixels) x output channels;
 // 64 channels = 8 waves (one workgroup per CU), 32 channels = 4 waves (two per CU).  Same sums: the autotuner picks freely.
 enum Wino2dTile { W2D_8x64 = 0, W2D_8x32 = 1, W2D_SHAPES = 2 };
+// conv_fold4_kernel tiles (CONV_TILE_FOLD4): 4 rows x 32 low-resolution pixels x output channels; four waves side by side, each 4 x 8 pixels
+// x all channels of the tile.  64 channels: 235 VGPRs, two workgroups per CU; 32 channels: 139 VGPRs, three.  Same sums.
+enum Fold4Tile { F4_4x64 = 0, F4_4x32 = 1 };
 // conv_foldx3_kernel tiles (CONV_TILE_FOLDX3): low-resolution patch rows x 32 pixels x output channels (waves M x N)
 enum FoldX3Tile { FX3_4x64 = 0 /* 4x1 */, FX3_8x64 = 1 /* 8x1 */, FX3_4x128 = 2 /* 4x2 */ };
 // conv_winox3_kernel tiles (CONV_TILE_WINO | CONV_TILE_X3): patch rows x 64 pixels x output channels, wave block TM x TN

@@ -134,6 +134,7 @@ void build_layers(film_t* h) {
     L.w_off = off; off += L.packed_rows() * L.cout; al();
     L.b_off = off; off += L.cout; al();
     if (L.has_fold()) { L.wf_off = off; off += (int64_t)9 * L.ctot() * L.cout; al(); }
+    if (L.has_fold() && L.ctot() % 16 == 0) { L.wf4_off = off; off += (int64_t)4 * L.ctot() * L.cout; al(); }
     if (L.has_halo()) { L.w43_off = off; off += L.packed_rows() * L.cout / 9 * 18; al(); }
     if (L.has_w2d()) { L.w2d_off = off; off += L.packed_rows() * L.cout / 9 * 24; al(); }
   }
@@ -335,6 +336,23 @@ static void pack_layer_group(film_t* h, const LayerPack& L, int group, int co0, 
             }
         df += kph * L.cout;
       }
+  }
+  // ---- difference form of upsample + 2x2 (group 0; conv_fold4_impl.h): [Cout/32][chunk8][plane 4][K half][32][4], planes S = ((W00 + W01) +
+  // W10) + W11, Sx = W01 + W11, Sy = W10 + W11, W11 (padding channels: zero rows)
+  if (group == 0 && L.wf4_off >= 0) {
+    float* d4 = base + L.wf4_off;
+    const size_t nk8 = (size_t)ct / 8;
+    for (int ci = 0; ci < ct; ++ci) {
+      const int ref = L.perm[ci];
+      for (int co = co0; co < co1; ++co) {
+        float w[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ref >= 0)
+          for (int tp = 0; tp < 4; ++tp) w[tp] = src[((size_t)tp * L.cin + ref) * L.cout + co];
+        const float pl[4] = {((w[0] + w[1]) + w[2]) + w[3], w[1] + w[3], w[2] + w[3], w[3]};
+        for (int q = 0; q < 4; ++q)
+          d4[((((size_t)(co / 32) * nk8 + ci / 8) * 4 + q) * 2 + (ci % 8) / 4) * 128 + (co % 32) * 4 + ci % 4] = pl[q];
+      }
+    }
   }
   // ---- nested Winograd copy (group 0, deep-K layers): U[mu][nu] = the F(2,3) transform along dy of the F(4,3)-transformed
   // kernel rows u_nu(dy) (the same u as the w43 copy), [Cout/32][chunk8][mu 4][nu 6][K half][32][4]

@@ -100,7 +100,7 @@ struct Planner {
       bad = true;
       bad_msg = "planner: channel mismatch at " + op.tag;
     }
-    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off; op.w43_off = L.w43_off; op.w2d_off = L.w2d_off;
+    op.w_off = L.w_off; op.b_off = L.b_off; op.wh_off = L.wh_off; op.ws_off = L.ws_off; op.ww_off = L.ww_off; op.wx_off = L.wx_off; op.wfx_off = L.wfx_off; op.wf4_off = L.wf4_off; op.w43_off = L.w43_off; op.w2d_off = L.w2d_off;
     if (h->opt_fold && L.wf_off >= 0 && op.nseg == 1 && segs[0].up && !(H & 1) && !(W & 1)) {
       // nearest x2 + 2x2 'same' conv == four phase convolutions on the low-resolution input: kernel tap (dy, dx) of
       // output (2y+py, 2x+px) reads input ((2y+py+dy)>>1, (2x+px+dx)>>1) = (y + (py&dy), x + (px&dx)), so phase
@@ -122,6 +122,14 @@ struct Planner {
         f.split = 2;   // precision mode bf16x3: one halo-staged patch, nine (tap, phase) steps (conv_foldx3_kernel)
         f.tile = FX3_4x64 | CONV_TILE_FOLDX3 | CONV_TILE_XCD;
         need_groups(4);
+      }
+      if (f.split == 0 && h->opt_fold4 && h->opt_precision == 0 && L.wf4_off >= 0 && segs[0].v.stride % 4 == 0 && segs[0].v.off % 4 == 0) {
+        // the difference form (conv_fold4_impl.h): four GEMMs over K on I, Dx, Dy, Dxy - 4 multiplies per low-resolution pixel, not 9.
+        // Its own summation family, chosen by the layer alone (every folded layer whose channels come in sixteens)
+        f.fold = 3;
+        f.w_off = L.wf4_off;
+        for (int q = 0; q < 4; ++q) f.fold_woff[q] = 0;
+        f.tile = (L.cout % 64 == 0 ? F4_4x64 : F4_4x32) | CONV_TILE_FOLD4 | CONV_TILE_XCD;
       }
       f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin;   // algorithmic FLOPs of the reference op
       f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout);
@@ -711,7 +719,7 @@ std::string plan_json(film_t* h, const Plan& P) {
     o << (i ? "," : "") << "{\"kind\":\"" << kKindName[op.kind] << "\",\"tag\":\"" << op.tag << "\",\"NB\":" << op.NB
       << ",\"H\":" << op.H << ",\"W\":" << op.W << ",\"ksize\":" << op.ksize << ",\"leaky\":" << op.leaky
       << ",\"Cout\":" << op.Cout << ",\"Ctot\":" << op.Ctot << ",\"tile\":" << op.tile << ",\"w_off\":" << op.w_off
-      << ",\"b_off\":" << op.b_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"w43_off\":" << op.w43_off << ",\"w2d_off\":" << op.w2d_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
+      << ",\"b_off\":" << op.b_off << ",\"wf4_off\":" << op.wf4_off << ",\"wh_off\":" << op.wh_off << ",\"halo\":" << op.halo << ",\"ws_off\":" << op.ws_off << ",\"split\":" << op.split << ",\"ww_off\":" << op.ww_off << ",\"wx_off\":" << op.wx_off << ",\"wfx_off\":" << op.wfx_off << ",\"w43_off\":" << op.w43_off << ",\"w2d_off\":" << op.w2d_off << ",\"wino\":" << op.wino << ",\"fold\":" << op.fold << ",\"ksplit\":" << op.ksplit << ",\"py\":" << op.py
       << ",\"px\":" << op.px << ",\"ftaps\":" << op.ftaps << ",\"tdy\":[" << op.tdy[0] << "," << op.tdy[1] << "," << op.tdy[2] << "," << op.tdy[3]
       << "],\"tdx\":[" << op.tdx[0] << "," << op.tdx[1] << "," << op.tdx[2] << "," << op.tdx[3] << "]"
       << ",\"fold_woff\":[" << op.fold_woff[0] << "," << op.fold_woff[1] << "," << op.fold_woff[2] << "," << op.fold_woff[3] << "]" << ",\"lane\":" << op.lane << ",\"xdeps\":["

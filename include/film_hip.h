@@ -168,10 +168,13 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  stages in the epilogue of the F(4,3) convolution in front of it (about 35 launches fewer per forward in all);
  *                  16: the RGB head (1x1 convolution, fusion.py:138-140) in the epilogue of the last decoder layer, whose
  *                  64-channel output is then never written.  0: one launch per reference op.  Drops the cached plans.
- *   "fold2x2" 0/1  1 (default): the decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) runs as four
- *                  sub-pixel phase convolutions on the low-resolution input with pre-summed weights (9 taps per 4
- *                  outputs instead of 16; an exact regrouping of the sum, rounding differs at the 1e-7 level).
- *                  0: one 2x2 convolution with the upsample folded into its gather.  Drops the cached plans.
+ *   "fold2x2" 0-2  the decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) on the LOW-resolution input.
+ *                  1 (default): in its difference form - four products per low-resolution pixel (with I, Dx = I - I(x+1),
+ *                  Dy = I - I(y+1), Dxy and the weight sums S, Sx, Sy, W11: out(2y+py, 2x+px) = S.I - px Sx.Dx - py Sy.Dy +
+ *                  py px W11.Dxy), conv_fold4_kernel; 2: as four sub-pixel phase convolutions with pre-summed weights (9 taps
+ *                  per 4 outputs instead of 16; the general kernel).  Both are exact regroupings of the sum, the rounding
+ *                  differs at the 1e-7 level.  0: one 2x2 convolution with the upsample folded into its gather.
+ *                  Drops the cached plans.
  *   "planar" 0/1   1 (default): an aligned-pyramid level (interpolator.py:167-183) is stored as three pixel-major planes -
  *                  warp(features of image 0), warp(features of image 1), the sixteen image / flow channels - each written
  *                  contiguously by its warp, and read by the decoder as three input segments in the reference's channel
@@ -195,6 +198,7 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "w43_shape" n  test knob: every convolution on conv_wino43_kernel that can run tile shape n (Wino43Tile, film_kernels.h)
  *                  does, instead of the autotuned shape; -1 (default) = autotuned.  Results cannot change.  Drops the cached plans.
  *   "w2d_shape" n  the same for conv_wino2d_kernel (Wino2dTile).
+ *   "fold4_shape" n  the same for conv_fold4_kernel (Fold4Tile).
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in limits: 64 GiB of
  *                  workspace, 4 GiB per buffer read through a whole-buffer 32-bit offset); frame pairs are independent,
  *                  results do not change */

@@ -55,10 +55,28 @@ def run_plan(plan: dict, packed: np.ndarray, x0: np.ndarray, x1: np.ndarray) -> 
             # nearest-x2 + 2x2 conv as four sub-pixel phases on the low-resolution grid (H, W); output 2H x 2W.
             # fold == 2: all phases in one op, phase q = py*2 + px, taps (a, b), a <= py, b <= px, raster order
             sg = op['segs'][0]
-            assert op['fold'] == 2 and len(op['segs']) == 1 and not sg['up'] and not sg['bmod'] and not op['leaky']
+            assert op['fold'] in (2, 3) and len(op['segs']) == 1 and not sg['up'] and not sg['bmod'] and not op['leaky']
             x = np.ascontiguousarray(_view(arena, sg['v'], nb, h, w))
             ct, co = op['Ctot'], op['Cout']
             outv = _view(arena, op['out'], nb, 2 * h, 2 * w)
+            if op['fold'] == 3:
+                # conv_fold4_kernel: the difference form.  Weights [Cout/32][chunk8][plane 4][K half][32][4], planes S, Sx, Sy, W11;
+                # G0 = S.I, G1 = Sx.Dx, G2 = Sy.Dy, G3 = W11.Dxy with Dx = I - I(x+1), Dy = I - I(y+1), Dxy = Dx - (I(y+1) - I(y+1,x+1))
+                # (zero beyond the bottom / right edge); out = G0, G0 - G1, G0 - G2, ((G0 - G1) - G2) + G3 (+ bias)
+                assert op['w_off'] == op['wf4_off'] and ct % 16 == 0 and co % 32 == 0
+                w4 = packed[op['w_off']:op['w_off'] + 4 * ct * co].reshape(co // 32, ct // 8, 4, 2, 32, 4)
+                w4 = w4.transpose(2, 1, 3, 5, 0, 4).reshape(4, ct, co)            # [plane][c = chunk*8 + half*4 + j][n = tile*32 + lane]
+                sh = lambda a, b: np.pad(x[:, a:, b:], ((0, 0), (0, a), (0, b), (0, 0)))     # noqa: E731
+                i00, i01, i10, i11 = x, sh(0, 1), sh(1, 0), sh(1, 1)
+                dx = i00 - i01
+                planes = [i00, dx, i00 - i10, dx - (i10 - i11)]
+                g = [(pl.reshape(-1, ct) @ w4[q]).reshape(nb, h, w, co) for q, pl in enumerate(planes)]
+                bias = packed[op['b_off']:op['b_off'] + co]
+                outv[:, 0::2, 0::2] = g[0] + bias
+                outv[:, 0::2, 1::2] = (g[0] - g[1]) + bias
+                outv[:, 1::2, 0::2] = (g[0] - g[2]) + bias
+                outv[:, 1::2, 1::2] = (((g[0] - g[1]) - g[2]) + g[3]) + bias
+                continue
             wfx = None
             if op.get('wfx_off', -1) >= 0:
                 # bf16x3 copy for conv_foldx3_kernel: [Cout][chunk16][9 (tap, phase) steps][plane][16] bf16

@@ -640,6 +640,47 @@ def test_fused_rgb_head_is_bit_identical(published):
     eu.close()
 
 
+def test_upsample_2x2_difference_form_against_the_phase_fold_and_the_plain_conv(published):
+    """The decoder's nearest-x2 upsample + 2x2 convolution (fusion.py:133-135) in its three forms - conv_fold4_kernel (option fold2x2 = 1,
+    default: four products per low-resolution pixel), four sub-pixel phases on the general kernel (2), one 2x2 convolution with the
+    upsample in its gather (0) - on the same inputs: every decoder level's 2x2 output and the image within float32 summation noise of
+    each other, on level sizes that are multiples of the 4 x 32 tile, ragged ones, and B > 1; both tile widths of the new kernel give
+    the same bits (the autotuner picks between them)."""
+    from film_hip.engine import FilmEngine
+    opt, w, _ = published
+    engs = {}
+    for mode in (1, 2, 0):
+        engs[mode] = FilmEngine(opt, device=0)
+        engs[mode].set_weights(w)
+        engs[mode].set_option('fold2x2', mode)
+    nlev = opt.fusion_pyramid_levels - 1
+    for (b, h, wd) in ((1, 256, 256), (2, 192, 320), (1, 320, 448), (1, 576, 960)):
+        ops = [op for op in engs[1].plan(b, h, wd)['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 2]
+        assert len(ops) == nlev and all(op['fold'] == 3 and (op['tile'] & 16384) for op in ops)
+        assert all(op['fold'] == 2 for op in engs[2].plan(b, h, wd)['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 2)
+        x0, x1 = _pair(b, h, wd, seed=h + wd)
+        img = {m: e.forward(x0, x1) for m, e in engs.items()}
+        for l in range(nlev):
+            u = {m: e.tap(f'fusion_up{l}') for m, e in engs.items()}
+            scale = max(1.0, float(np.abs(u[0]).max()))
+            d12, d10 = float(np.abs(u[1] - u[2]).max()), float(np.abs(u[1] - u[0]).max())
+            print(f'{b}x{h}x{wd} fusion_up{l}: |fold4 - phases| {d12:.2e}, |fold4 - plain| {d10:.2e}, max|value| {scale:.2e}')
+            assert d12 < 2e-5 * scale and d10 < 2e-5 * scale, (b, h, wd, l)
+        assert np.abs(img[1] - img[2]).max() < 2e-5 and np.abs(img[1] - img[0]).max() < 2e-5
+    # the two tile widths of conv_fold4_kernel: same k-ordered sums
+    x0, x1 = _pair(1, 256, 256, seed=5)
+    ref = engs[1].forward(x0, x1)
+    for e in engs.values():
+        e.close()
+    for shape in (0, 1):
+        e = FilmEngine(opt, device=0)
+        e.set_weights(w)
+        e.set_option('fold4_shape', shape)
+        assert all((op['tile'] & 15) == shape for op in e.plan(1, 256, 256)['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 2)
+        assert np.array_equal(e.forward(x0, x1), ref), shape
+        e.close()
+
+
 def test_tune_cache_carries_autotune_choices_to_the_next_engine(published, tmp_path, monkeypatch):
     """$FILM_TUNE_CACHE: the first engine measures the tile candidates of every conv shape and writes its choices, the
     second one reads them and skips the measurements - same tiles in its plan, same bits, a faster first call."""

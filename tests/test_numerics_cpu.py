@@ -126,3 +126,39 @@ def test_subpixel_fold_of_upsample_and_2x2_conv():
                     got[py::2, px::2] += xp[a:a + h, b:b + w] @ wsum
                     steps += 1
     assert steps == 9 and np.abs(got - ref).max() < 1e-12
+
+
+def test_difference_form_of_upsample_and_2x2_conv():
+    """conv_fold4_kernel's identity (conv_fold4_impl.h): with I = 0 beyond the bottom / right edge, Dx = I - I(x+1), Dy = I - I(y+1),
+    Dxy = Dx - (I(y+1) - I(y+1, x+1)) and the weight sums S = W00 + W01 + W10 + W11, Sx = W01 + W11, Sy = W10 + W11:
+    out(2y, 2x) = S.I, out(2y, 2x+1) = S.I - Sx.Dx, out(2y+1, 2x) = S.I - Sy.Dy, out(2y+1, 2x+1) = S.I - Sx.Dx - Sy.Dy + W11.Dxy -
+    four products per low-resolution pixel for the reference op's sixteen (fusion.py:133-135) - in float64 exactly, and in float32
+    within the rounding of a sum of that length."""
+    rng = np.random.default_rng(5)
+    h, w, ci, co = 6, 9, 24, 5
+    x = rng.standard_normal((h, w, ci))
+    k = rng.standard_normal((2, 2, ci, co)) * 0.2
+    up = np.repeat(np.repeat(x, 2, axis=0), 2, axis=1)
+    pad = np.zeros((2 * h + 1, 2 * w + 1, ci))
+    pad[:2 * h, :2 * w] = up
+    ref = np.zeros((2 * h, 2 * w, co))
+    for dy in range(2):
+        for dx in range(2):
+            ref += pad[dy:dy + 2 * h, dx:dx + 2 * w] @ k[dy, dx]
+    for dt, tol in ((np.float64, 1e-12), (np.float32, 2e-5)):
+        xp = np.zeros((h + 1, w + 1, ci), dt)
+        xp[:h, :w] = x
+        kk = k.astype(dt)
+        i00, i01, i10, i11 = xp[:h, :w], xp[:h, 1:], xp[1:, :w], xp[1:, 1:]
+        dxp = i00 - i01
+        planes = (i00, dxp, i00 - i10, dxp - (i10 - i11))
+        wsum = (((kk[0, 0] + kk[0, 1]) + kk[1, 0]) + kk[1, 1], kk[0, 1] + kk[1, 1], kk[1, 0] + kk[1, 1], kk[1, 1])
+        g = [p @ ws for p, ws in zip(planes, wsum)]
+        assert all(v.dtype == dt for v in g)
+        got = np.zeros((2 * h, 2 * w, co), dt)
+        got[0::2, 0::2] = g[0]
+        got[0::2, 1::2] = g[0] - g[1]
+        got[1::2, 0::2] = g[0] - g[2]
+        got[1::2, 1::2] = ((g[0] - g[1]) - g[2]) + g[3]
+        assert np.abs(got - ref).max() < tol, (dt, np.abs(got - ref).max())
+

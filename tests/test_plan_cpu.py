@@ -150,6 +150,39 @@ def test_plan_interpreter_matches_oracle_tiny(tiny_weights, b, h, w):
     assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 1e-5
 
 
+@pytest.mark.parametrize('mode', [0, 1, 2])
+def test_upsample_2x2_layer_forms_by_option(tiny_weights, mode):
+    """Option "fold2x2": 1 (default) = the difference form on conv_fold4_kernel (fold = 3, tile flag 16384, the S / Sx / Sy / W11 copy),
+    2 = four sub-pixel phases on the general kernel (fold = 2), 0 = one 2x2 convolution with the upsample in its gather - every form
+    interpreted from its own packed weights against the oracle (fusion.py:133-135)."""
+    from film_hip.engine import FilmEngine, FilmError
+    from film_hip.options import TINY
+    from oracle import film_oracle as fo
+    import plan_interp as pi
+    eng = FilmEngine(TINY, device=-1)
+    eng.set_weights(tiny_weights)
+    eng.set_option('pack_groups', 4)     # every layout copy, so that the interpreter can check all of them
+    eng.set_option('fold2x2', mode)
+    plan = eng.plan(1, 32, 48)
+    ups = [op for op in plan['ops'] if op['kind'] == 'conv_mfma' and op['ksize'] == 2]
+    assert len(ups) == TINY.fusion_pyramid_levels - 1
+    for op in ups:
+        assert op['fold'] == {0: 0, 1: 3, 2: 2}[mode]
+        assert bool(op['tile'] & 16384) == (mode == 1)
+        assert (op['segs'][0]['up'] != 0) == (mode == 0)
+        if mode == 1:
+            assert op['w_off'] == op['wf4_off'] >= 0
+    rng = np.random.default_rng(11)
+    x0 = rng.random((1, 32, 48, 3), dtype=np.float32)
+    x1 = rng.random((1, 32, 48, 3), dtype=np.float32)
+    arena = pi.run_plan(plan, eng.export_layouts(), x0, x1)
+    want = fo.film_forward(x0, x1, tiny_weights, oracle_options(TINY))
+    assert np.abs(pi.tap(plan, arena, 'out') - want).max() < 1e-5
+    with pytest.raises(FilmError):
+        eng.set_option('fold2x2', 3)
+    eng.close()
+
+
 @pytest.fixture(scope='module')
 def published_packed():
     """(weights, plan-only engine of the published net with all four layout groups packed, the exported layout blob):

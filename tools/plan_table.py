@@ -16,6 +16,8 @@ def family(op):
         return op['kind']
     if t & 8192:
         return 'conv_wino2d F(4,3)x x F(2,3)y'
+    if t & 16384:
+        return 'conv_fold4 (upsample + 2x2, difference form)'
     if t & 1024:
         return 'conv_foldx3'
     if t & 256:
