@@ -19,6 +19,7 @@
 //   * two register stages + two LDS stages: the loads of step s+2 are issued before the MFMAs of step s, the
 //     registers of step s+1 go to LDS after them, one barrier per step.
 #pragma once
+#include <atomic>
 #include <type_traits>
 #include <utility>
 
@@ -37,6 +38,20 @@ enum : int {
 typedef __amdgpu_buffer_rsrc_t conv_rsrc_t;
 __device__ __forceinline__ conv_rsrc_t conv_make_rsrc(const void* p) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, -1, 0x00020000);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function ON the current device and is idempotent: set on the first launch
+// per (kernel instantiation, device).  The "already set" flags are atomics (relaxed is enough: a second thread that misses the flag
+// only repeats the call) - several handles on several host threads may launch the same instantiation (include/film_hip.h).
+struct ConvLdsAttrFlags { std::atomic<bool> set[64]; };
+inline hipError_t conv_allow_dynamic_lds(const void* kern, ConvLdsAttrFlags& flags, int bytes) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const bool tracked = dev >= 0 && dev < 64;
+  if (tracked && flags.set[dev].load(std::memory_order_relaxed)) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess && tracked) flags.set[dev].store(true, std::memory_order_relaxed);
+  return e;
 }
 
 __device__ __forceinline__ bf4 conv_buf_load(conv_rsrc_t rsrc, unsigned voff, unsigned soff) {
@@ -308,14 +323,8 @@ hipError_t conv_buf_launch(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)(BM + BN) * 16 * sizeof(float);
   auto kern = conv_buf_kernel<BM, BN, WGM, WGN, FLAGS>;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
+    if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, (int)lds); e != hipSuccess) return e;
   }
   if (p.ksplit > 1 && p.fold) return hipErrorInvalidValue;
   if (p.ksplit > 1 ? (p.Cout % 4 || (reinterpret_cast<uintptr_t>(p.part) & 15)) : (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15))) return hipErrorInvalidValue;   // dwordx4 stores

@@ -266,14 +266,8 @@ hipError_t conv_foldx3_launch(const ConvParams& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   auto kern = conv_foldx3_kernel<TH, BN, WGM, WGN, FLAGS>;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
+    if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, (int)lds); e != hipSuccess) return e;
   }
   if (p.nseg != 1 || p.seg[0].up) return hipErrorInvalidValue;
   const int ntx = (p.W + 31) / 32, nty = (p.H + TH - 1) / TH;

@@ -275,14 +275,8 @@ hipError_t conv_halo_launch(const ConvParams& p, hipStream_t s) {
   constexpr size_t lds = (2 * (size_t)(TH + 2) * 40 * 16 + 3 * (size_t)BN * 16) * sizeof(float);
   auto kern = conv_halo_kernel<TH, BN, WGM, WGN, FLAGS>;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
+    if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, (int)lds); e != hipSuccess) return e;
   }
   const int ntx = (p.W + 31) / 32, nty = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN);

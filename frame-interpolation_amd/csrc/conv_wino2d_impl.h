@@ -160,8 +160,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   };
   // split-K (ConvParams::ksplit, film_kernels.h; round 5): blockIdx.z = split z sums the super-chunks [sc0, sc1) of the K loop and
   // writes RAW partial sums to part[z][pixel][Cout]; conv_splitk_reduce_kernel adds them in split order with the bias and the
-  // activation.  For the deep-K layers of the levels whose workgroup count leaves the chip half empty in its last round (72x120:
-  // 2304 workgroups on 512 slots = 4.5 rounds of 0.5 ms) or does not fill it at all (36x60: 640 workgroups).
+  // activation.  The planner uses it for the K >= 768 layers of levels with <= 4096 pixels, whose workgroups do not fill the chip (36x60:
+  // 640 workgroups on 512 slots); on the 72x120 level (2304 workgroups = 4.5 rounds) two K ranges gained 2-4 % stand-alone and nothing in
+  // the forward (profiles/r05_w2d_splitk.log): not used there.
   const int ksp = p.ksplit > 1 ? p.ksplit : 1;
   const int nsc_all = p.Ctot >> 4;
   int sc0 = 0, sc1 = nsc_all;
@@ -558,14 +559,8 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   for (int i = 0; i < p.nseg; ++i)
     if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
   auto kern = conv_wino2d_kernel<BN, FLAGS>;
-  static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-    if (e != hipSuccess) return e;
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
+  static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
+  if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, 144 * 1024); e != hipSuccess) return e;
   const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);

@@ -313,14 +313,8 @@ hipError_t conv_winox3_launch(const ConvParams& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS");
   auto kern = conv_winox3_kernel<TH, BN, TM, TN, FLAGS>;
   if constexpr (lds > 64 * 1024) {
-    static bool attr_set[64] = {};  // per device: the attribute belongs to the function ON the current device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      if (dev >= 0 && dev < 64) attr_set[dev] = true;
-    }
+    static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
+    if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, (int)lds); e != hipSuccess) return e;
   }
   const int ntx = (p.W + 63) / 64, nty = (p.H + TH - 1) / TH;
   dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN);

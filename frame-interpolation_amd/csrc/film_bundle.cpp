@@ -27,7 +27,6 @@
 #include <sys/stat.h>
 
 #include <algorithm>
-#include <regex>
 #include <set>
 
 #include "film_internal.h"
@@ -164,21 +163,47 @@ Entry parse_entry(const uint8_t* p, size_t n) {
   return e;
 }
 
-// object-graph attribute path (without the VARIABLE_VALUE suffix) -> canonical tensor name, "" if it is not a film_net weight
-std::string canonical_name(const std::string& path, int specialized_levels) {
-  static const std::regex feat("(?:^|/)extract_sublevels/convs/([0-9]+)/(kernel|bias)$");
-  static const std::regex flow("(?:^|/)_predictors/([0-9]+)/_convs/([0-9]+)/(kernel|bias)$");
-  static const std::regex fuse("(?:^|/)convs/([0-9]+)/([0-9]+)/(kernel|bias)$");
-  static const std::regex outc("(?:^|/)output_conv/(kernel|bias)$");
-  std::smatch m;
-  auto num = [](const std::string& s) { return std::to_string(std::stol(s)); };
-  if (std::regex_search(path, m, feat)) return "feat_net/sub_extractor/cfeat_conv_" + num(m[1]) + "/" + m[2].str();
-  if (std::regex_search(path, m, flow)) {
-    const long p = std::stol(m[1]);
-    return "predict_flow/" + (p < specialized_levels ? "flow_predictor_" + std::to_string(p) : std::string("flow_predictor_shared")) + "/conv_" + num(m[2]) + "/" + m[3].str();
+// object-graph attribute path (without the VARIABLE_VALUE suffix) -> canonical tensor name, "" if it is not a film_net weight.
+// The keys come from the file: a hand-written suffix parser over the '/'-separated components (std::regex recurses once per matched
+// character - a key with a 100 000-digit run overflowed the stack; round-5 ADVICE).  Keys longer than kMaxKeyLen and numeric
+// components longer than 9 digits are not film_net weights.
+constexpr size_t kMaxKeyLen = 4096;
+
+bool small_number(const std::string& s, long* out) {
+  if (s.empty() || s.size() > 9) return false;
+  long v = 0;
+  for (char c : s) {
+    if (c < '0' || c > '9') return false;
+    v = v * 10 + (c - '0');
   }
-  if (std::regex_search(path, m, fuse)) return "fusion/convs_" + num(m[1]) + "_" + num(m[2]) + "/" + m[3].str();
-  if (std::regex_search(path, m, outc)) return "fusion/output_conv/" + m[1].str();
+  *out = v;
+  return true;
+}
+
+std::string canonical_name(const std::string& path, int specialized_levels) {
+  if (path.size() > kMaxKeyLen) return "";
+  std::vector<std::string> c;   // components, last first; at most the six the longest pattern needs
+  size_t end = path.size();
+  while (c.size() < 6) {
+    const size_t slash = end == 0 ? std::string::npos : path.rfind('/', end - 1);
+    c.push_back(path.substr(slash == std::string::npos ? 0 : slash + 1, end - (slash == std::string::npos ? 0 : slash + 1)));
+    if (slash == std::string::npos) break;
+    end = slash;
+  }
+  const size_t n = c.size();
+  if (n < 2 || (c[0] != "kernel" && c[0] != "bias")) return "";
+  long a = 0, b = 0;
+  // .../extract_sublevels/convs/<i>/(kernel|bias)
+  if (n >= 4 && c[2] == "convs" && c[3] == "extract_sublevels" && small_number(c[1], &a))
+    return "feat_net/sub_extractor/cfeat_conv_" + std::to_string(a) + "/" + c[0];
+  // .../_predictors/<p>/_convs/<j>/(kernel|bias)
+  if (n >= 5 && c[2] == "_convs" && c[4] == "_predictors" && small_number(c[3], &a) && small_number(c[1], &b))
+    return "predict_flow/" + (a < specialized_levels ? "flow_predictor_" + std::to_string(a) : std::string("flow_predictor_shared")) + "/conv_" + std::to_string(b) + "/" + c[0];
+  // .../convs/<i>/<j>/(kernel|bias)
+  if (n >= 4 && c[3] == "convs" && small_number(c[2], &a) && small_number(c[1], &b))
+    return "fusion/convs_" + std::to_string(a) + "_" + std::to_string(b) + "/" + c[0];
+  // .../output_conv/(kernel|bias)
+  if (c[1] == "output_conv") return "fusion/output_conv/" + c[0];
   return "";
 }
 
@@ -242,6 +267,7 @@ struct Bundle {
           int endianness = 0;
           for (const PbField& f : pb_decode(v, n)) { if (f.field == 1) num_shards = (int)f.v; else if (f.field == 2) endianness = (int)f.v; }
           if (endianness != 0) bad("big-endian bundles are not supported");
+          if (num_shards < 1 || num_shards > 99999) bad(prefix + ".index: header names " + std::to_string(num_shards) + " shards");
           return;
         }
         entries[key] = parse_entry(v, n);
@@ -256,6 +282,7 @@ struct Bundle {
     if (e.dtype != 1) bad(key + ": dtype " + std::to_string(e.dtype) + " is not DT_FLOAT");
     int64_t n = 1;
     for (int64_t s : e.shape) n *= s;
+    if (e.shard < 0 || e.shard >= num_shards) bad(key + ": shard " + std::to_string(e.shard) + " of a bundle with " + std::to_string(num_shards));
     if (n < 0 || e.size != (uint64_t)n * 4) bad(key + ": " + std::to_string(e.size) + " bytes for shape " + shape_str(e.shape));
     FILE*& f = shards[e.shard];
     if (!f) {
@@ -349,13 +376,24 @@ extern "C" int film_load_bundle(film_t* h, const char* path, int verify_crc, cha
       return fail(h, FILM_ERR_NOTFOUND, "%s: no variable found for %s%s (%d of %d tensors); keys look like %s", prefix.c_str(), still[0].c_str(),
                   still.size() > 1 ? ", ..." : "", (int)still.size(), (int)specs.size(), var_keys.empty() ? "(none)" : var_keys[0].c_str());
 
+    // every tensor has been read, checked and matched before the first one is handed over; should a hand-over still fail, say that the
+    // handle now holds a mix of two weight sets (round-5 ADVICE) instead of passing the inner message on alone
+    int n_set = 0;
     for (const std::string& n : spec_order) {
       const std::vector<int64_t>& shp = specs[n];
       const int rc = film_set_weight(h, n.c_str(), out[n].data(), shp.data(), (int)shp.size());
-      if (rc != FILM_OK) return rc;
+      if (rc != FILM_OK) {
+        const std::string inner = film_last_error(h);
+        return fail(h, rc, "film_load_bundle: %s (after %d of %d tensors: the weights of this handle are now UNDEFINED - load a complete set before using it)",
+                    inner.c_str(), n_set, (int)spec_order.size());
+      }
+      ++n_set;
     }
     const int rc = film_finalize(h);
-    if (rc != FILM_OK) return rc;
+    if (rc != FILM_OK) {
+      const std::string inner = film_last_error(h);
+      return fail(h, rc, "film_load_bundle: %s (all %d tensors were handed over; film_finalize failed: the handle cannot run until it succeeds)", inner.c_str(), n_set);
+    }
 
     // report: one line per tensor, "<name>\t<rule>\t<checkpoint key>\n" (rule = path | shape); a tensor placed by its shape is a
     // (unique-shape) guess, not a name match - callers should say so (the Python wrapper logs a warning)

@@ -867,7 +867,7 @@ namespace {
 // at most once by the other lane - see there for why that matters to a graph replay).  Called inside a stream capture (graph = 1:
 // the events become graph edges) or directly (graph = 2: real events; one set per plan, re-recorded every forward - a wait refers
 // to the record that precedes it in program order, and everything of forward n + 1 is ordered behind forward n's join on `main`).
-hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main) {
+hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main, bool capturing) {
   const size_t nops = P->ops.size();
   if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
   hipError_t ev_err = hipSuccess;
@@ -899,6 +899,11 @@ hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main) {
   if (two_lanes && le == hipSuccess) {
     le = hipEventRecord(event_of(nops + 1), h->stream2);
     if (le == hipSuccess) le = hipStreamWaitEvent(main, event_of(nops + 1), 0);
+  } else if (two_lanes && !capturing) {
+    // a launch or an event call failed behind the fork: the side stream may still hold lane-1 work that nothing on `main` is ordered
+    // behind.  Drain it before the error goes back to the caller, who may reuse or free the buffers of this plan (round-5 ADVICE).
+    // (inside a capture the streams carry no work: the capture itself is invalidated and ended by the caller)
+    (void)hipStreamSynchronize(h->stream2);
   }
   return le == hipSuccess ? ev_err : le;
 }
@@ -941,7 +946,7 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
       // capture on the handle's own stream, replay on whichever stream the caller wants
       HIPCHK(h, hipStreamSynchronize(s));
       HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-      const hipError_t le = issue_lanes(h, P, h->stream);
+      const hipError_t le = issue_lanes(h, P, h->stream, true);
       hipError_t ce = hipStreamEndCapture(h->stream, &P->graph);
       if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed during capture: %s", hipGetErrorString(le));
       HIPCHK(h, ce);
@@ -951,7 +956,7 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
   } else if (h->opt_graph == 2 && h->opt_lanes != 0) {
     // the DEFAULT: the same two lanes and the same event edges, launched directly - lane 0 on the caller's stream, lane 1 on the
     // handle's side stream (issue_lanes; why not a hipGraph by default: film_internal.h, opt_graph)
-    const hipError_t le = issue_lanes(h, P, s);
+    const hipError_t le = issue_lanes(h, P, s, false);
     if (le != hipSuccess) return fail(h, FILM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le));
   } else {
     for (const OpDesc& op : P->ops) HIPCHK(h, launch_op(op, P->arena, h->packed_dev, s));

@@ -196,6 +196,9 @@ class FilmEngine:
         need = ctypes.c_int64()
         buf = ctypes.create_string_buffer(1 << 16)
         self._check(self._lib.film_load_bundle(self._h, os.fsencode(path), 1 if verify else 0, buf, len(buf), ctypes.byref(need)))
+        if need.value > len(buf):    # the report did not fit (long checkpoint keys): read the bundle once more with a buffer that holds it
+            buf = ctypes.create_string_buffer(int(need.value) + 1)
+            self._check(self._lib.film_load_bundle(self._h, os.fsencode(path), 1 if verify else 0, buf, len(buf), ctypes.byref(need)))
         rep = {}
         # (checkpoint keys are bytes of the file: with verify=False a damaged index can hand back anything)
         for line in buf.value.decode('utf-8', 'replace').splitlines():
@@ -207,7 +210,7 @@ class FilmEngine:
             import logging
             logging.getLogger('film_hip.tf_bundle').warning(
                 '%s: %d of %d tensors were not found under a known object-graph path and were placed by their (unique) shape: %s',
-                path, len(by_shape), len(rep), ', '.join(f'{n} <- {rep[n][1]}' for n in by_shape))
+                path, len(by_shape), len(rep), ', '.join(f'{n} <- {rep[n][1] if len(rep[n][1]) <= 160 else rep[n][1][:157] + "..."}' for n in by_shape))
         self._load_tune_cache()
         return rep
 

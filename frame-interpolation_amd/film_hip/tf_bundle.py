@@ -354,14 +354,19 @@ class BundleReader:
 
 
 # ------------------------------------------------------------------------------------------------ film_net key mapping
-_RE_FEAT = re.compile(r'(?:^|/)extract_sublevels/convs/(\d+)/(kernel|bias)$')
-_RE_FLOW = re.compile(r'(?:^|/)_predictors/(\d+)/_convs/(\d+)/(kernel|bias)$')
-_RE_FUSE = re.compile(r'(?:^|/)convs/(\d+)/(\d+)/(kernel|bias)$')
+_RE_FEAT = re.compile(r'(?:^|/)extract_sublevels/convs/([0-9]+)/(kernel|bias)$')
+_RE_FLOW = re.compile(r'(?:^|/)_predictors/([0-9]+)/_convs/([0-9]+)/(kernel|bias)$')
+_RE_FUSE = re.compile(r'(?:^|/)convs/([0-9]+)/([0-9]+)/(kernel|bias)$')
 _RE_OUT = re.compile(r'(?:^|/)output_conv/(kernel|bias)$')
+
+
+MAX_KEY_LEN = 4096      # longer keys, and numeric components of more than 9 digits, are not film_net weights (the native reader's limits)
 
 
 def canonical_name(path: str, specialized_levels: int) -> Optional[str]:
     """Object-graph attribute path (without the VARIABLE_VALUE suffix) -> canonical tensor name, or None."""
+    if len(path) > MAX_KEY_LEN or any(len(c) > 9 and c.isdigit() for c in path.rsplit('/', 5)[1:]):
+        return None
     m = _RE_FEAT.search(path)
     if m:
         return f'feat_net/sub_extractor/cfeat_conv_{int(m.group(1))}/{m.group(2)}'

@@ -19,7 +19,10 @@
  * Every function returns 0 on success or a negative FILM_ERR_* code; the message is
  * available from film_last_error().  A handle owns one device, one stream, the packed
  * weights and a per-(B,H,W) cached execution plan + workspace.  Handles are not
- * thread-safe; several handles may coexist.
+ * thread-safe - ONE in-flight issuer per handle: a forward launches on the caller's stream and on
+ * the handle's side stream with one set of events per plan, so two threads (or two streams) must
+ * not issue forwards of the same handle concurrently.  Several handles may coexist, also on
+ * several host threads (tests/test_host_threads_cpu.py runs that under ThreadSanitizer).
  */
 #ifndef FILM_HIP_H_
 #define FILM_HIP_H_

@@ -295,6 +295,44 @@ def test_native_loader_errors_and_shape_rule(tmp_path, tiny_weights, caplog):
     assert ei.value.code == -6
 
 
+def test_hostile_keys_do_not_reach_a_recursive_matcher(tmp_path, tiny_weights):
+    """Round-5 ADVICE: a CRC-valid bundle whose key holds a 100 000-digit run (or is 1 MB long) used to overflow the stack inside
+    std::regex.  The key matcher is a hand-written suffix parser now: such keys are simply not film_net weights (here: extra entries
+    beside a complete weight set, and - second bundle - IN PLACE of a weight, which must surface as 'no variable found')."""
+    from film_hip import tf_bundle as tb
+    from film_hip import weights as W
+    from film_hip.engine import FilmError
+    from film_hip.options import TINY
+    names = [n for spec, _, _ in W.weight_specs(TINY) for n in (spec + '/kernel', spec + '/bias')]
+    good = {tb.checkpoint_key(n, TINY): tiny_weights[n] for n in names}
+    digits = '1' * 100000
+    hostile = {
+        f'layer_with_weights-0/extract_sublevels/convs/{digits}/kernel{tb.VAR_SUFFIX}': np.zeros((1,), np.float32),
+        f'layer_with_weights-1/_predictors/{digits}/_convs/{digits}/bias{tb.VAR_SUFFIX}': np.zeros((1,), np.float32),
+        f'layer_with_weights-2/convs/0/{digits}/kernel{tb.VAR_SUFFIX}': np.zeros((1,), np.float32),
+        'x/' * 500000 + f'output_conv/kernel{tb.VAR_SUFFIX}': np.zeros((1,), np.float32),
+        f'layer_with_weights-2/convs/0000000000/0/kernel{tb.VAR_SUFFIX}': np.zeros((1,), np.float32),     # ten digits: over the cap
+    }
+    for path in hostile:
+        assert tb.canonical_name(path[:-len(tb.VAR_SUFFIX)], TINY.specialized_levels) is None
+    prefix = str(tmp_path / 'variables' / 'variables')
+    bw.write_bundle(prefix, {**good, **hostile}, object_graph=False)
+    ref = _native(TINY)
+    ref.set_weights(tiny_weights)
+    eng = _native(TINY)
+    eng.load_bundle(str(tmp_path))
+    assert np.array_equal(eng.export_packed(), ref.export_packed())
+    assert tb.load_film_weights(prefix, TINY).keys() == tiny_weights.keys()
+    victim = tb.checkpoint_key('feat_net/sub_extractor/cfeat_conv_1/kernel', TINY)
+    renamed = {(k.replace('/convs/1/', f'/convs/{digits}/') if k == victim else k): v for k, v in good.items()}
+    bw.write_bundle(prefix, renamed, object_graph=False)
+    try:   # the tensor behind the unusable key: placed by its shape where that is unique (and reported in full), refused otherwise
+        rep = _native(TINY).load_bundle(str(tmp_path))
+        assert rep['feat_net/sub_extractor/cfeat_conv_1/kernel'][0] == 'shape' and len(rep['feat_net/sub_extractor/cfeat_conv_1/kernel'][1]) > 100000
+    except FilmError as e:
+        assert 'no variable found' in str(e) or 'refusing to guess' in str(e)
+
+
 def test_interpolator_takes_the_native_path_for_a_savedmodel_directory(tmp_path, tiny_weights, monkeypatch):
     """eval.interpolator.Interpolator(<SavedModel dir>) goes through film_load_bundle - not through the Python parser."""
     from film_hip import tf_bundle as tb
