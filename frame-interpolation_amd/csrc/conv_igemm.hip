@@ -105,9 +105,20 @@ static hipError_t launch_wino(const ConvParams& p, int shape, hipStream_t s) {
 
 #endif   // FILM_EXTRA_FAMILIES
 
+// The default library holds the SEVEN conv_wino43_kernel tiles film_w43_shape_built() names (film_kernels.h; a default plan runs this
+// kernel on two layers of a 256x256 frame's 32x32 level only - the others were 27 instantiations nobody could select without an
+// option); the FILM_EXTRA_FAMILIES flavour holds all seventeen, for the tile-shape tests and the "winograd" = 3 / "wino2d" = 0 A/B runs.
 template <int F>
 static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
+    case W43_Q16_4x64_T21_P2: return conv_wino43_launch<4, 64, 2, 1, F | W43_F_PF2, 16>(p, s);
+    case W43_Q16_4x32_T11_P2: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_PF2, 16>(p, s);
+    case W43_Q16_4x64_N1_P2: return conv_wino43_launch<4, 64, 1, 1, F | W43_F_PF2, 16, 1>(p, s);
+    case W43_Q8_8x64_T21_P2: return conv_wino43_launch<8, 64, 2, 1, F | W43_F_PF2, 8>(p, s);
+    case W43_Q8_8x64_N1_P2: return conv_wino43_launch<8, 64, 1, 1, F | W43_F_PF2, 8, 1>(p, s);
+    case W43_Q8_8x32_T11_BG: return conv_wino43_launch<8, 32, 1, 1, F | W43_F_BG, 8>(p, s);
+    case W43_Q8_8x32_T11_P2: return conv_wino43_launch<8, 32, 1, 1, F | W43_F_PF2, 8>(p, s);
+#ifdef FILM_EXTRA_FAMILIES
     case W43_4x64_T21: return conv_wino43_launch<4, 64, 2, 1, F>(p, s);
     case W43_4x64_T12: return conv_wino43_launch<4, 64, 1, 2, F>(p, s);
     case W43_4x32_T11: return conv_wino43_launch<4, 32, 1, 1, F>(p, s);
@@ -115,16 +126,10 @@ static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
     case W43_Q16_4x64_T12: return conv_wino43_launch<4, 64, 1, 2, F, 16>(p, s);
     case W43_Q16_4x32_T11: return conv_wino43_launch<4, 32, 1, 1, F, 16>(p, s);
     case W43_Q16_4x64_N1: return conv_wino43_launch<4, 64, 1, 1, F, 16, 1>(p, s);
-    case W43_Q16_4x64_T21_P2: return conv_wino43_launch<4, 64, 2, 1, F | W43_F_PF2, 16>(p, s);
     case W43_Q16_4x64_T12_P2: return conv_wino43_launch<4, 64, 1, 2, F | W43_F_PF2, 16>(p, s);
-    case W43_Q16_4x32_T11_P2: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_PF2, 16>(p, s);
-    case W43_Q16_4x64_N1_P2: return conv_wino43_launch<4, 64, 1, 1, F | W43_F_PF2, 16, 1>(p, s);
     case W43_Q16_4x32_T11_BG: return conv_wino43_launch<4, 32, 1, 1, F | W43_F_BG, 16>(p, s);
-    case W43_Q8_8x64_T21_P2: return conv_wino43_launch<8, 64, 2, 1, F | W43_F_PF2, 8>(p, s);
     case W43_Q8_8x64_T12_P2: return conv_wino43_launch<8, 64, 1, 2, F | W43_F_PF2, 8>(p, s);
-    case W43_Q8_8x64_N1_P2: return conv_wino43_launch<8, 64, 1, 1, F | W43_F_PF2, 8, 1>(p, s);
-    case W43_Q8_8x32_T11_BG: return conv_wino43_launch<8, 32, 1, 1, F | W43_F_BG, 8>(p, s);
-    case W43_Q8_8x32_T11_P2: return conv_wino43_launch<8, 32, 1, 1, F | W43_F_PF2, 8>(p, s);
+#endif
     default: return hipErrorInvalidValue;
   }
 }
@@ -134,6 +139,7 @@ static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
     case W2D_8x64: return conv_wino2d_launch<64, F>(p, s);
     case W2D_8x32: return conv_wino2d_launch<32, F>(p, s);
+    case W2D_8x32_S2: return conv_wino2d_launch<32, F, 2>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -46,7 +46,10 @@
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W2D_F_XFIRST = 32,      // tools only: x transform per row, then the y combine (120 VALU per chunk; the bits of conv_wino2d_r3_kernel)
+enum { W2D_F_CHAIN = 64,       // a workgroup walks ConvParams::chain consecutive pixel tiles (same output channels): the DMA cursor and the weight
+                               // requests run on into the next tile while this one finishes, the epilogue's exchange buffers lie BEHIND the stages
+                               // (see "chained tiles" below).  Same sums, same bits.
+       W2D_F_XFIRST = 32,      // tools only: x transform per row, then the y combine (120 VALU per chunk; the bits of conv_wino2d_r3_kernel)
        W2D_DBG_NOXF = 256,     // timing ablations (tools only; results are wrong on purpose): no transforms (raw pixels as fragments)
        W2D_DBG_NODMA = 512,    // no DMA requests in the K loop
        W2D_DBG_NOB = 1024,     // no weight requests in the K loop
@@ -63,14 +66,16 @@ __device__ __forceinline__ void w2d_for_each(F&& f, std::integer_sequence<int, G
 
 // BN = 32 NG output channels per workgroup, one wave per (mu, 32 channels): 4 NG waves, two waves per SIMD either way (BN = 64: one
 // workgroup of 8 waves per CU; BN = 32: two of 4 - their prologues / epilogues overlap the other's K loop: the usual winner)
-template <int BN, int FLAGS>
+template <int BN, int FLAGS, int NS_ = 3>
 __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_wino2d_kernel(ConvParams p) {
   constexpr int QW = 8, TH = 8, HR = TH + 2, PXW = 4 * QW, PW = PXW + 2;
   constexpr int NG = BN / 32, NW = 4 * NG;
   constexpr int RP4 = 148, MO4 = 36, CO4 = 9;   // row pitch, m stride, piece stride in 16-byte slots (2368, 576, 144 bytes)
   constexpr int NREQ = 24;                      // DMA requests (1 KB each) per stage: 10 rows x 148 slots = 1480 <= 1536
   constexpr int STAGE4 = NREQ * 64;             // slots per stage
-  constexpr int NS = 3;                         // stages
+  constexpr int NS = NS_;                       // stages (3; the chained 32-channel tile: 2, so that two workgroups with their exchange buffers fit a CU)
+  constexpr bool CHAIN = (FLAGS & W2D_F_CHAIN) != 0;
+  static_assert(NS == 2 || NS == 3, "stages");
   constexpr int IPW = NREQ / NW;                // requests per wave and super-chunk
   static_assert(NREQ % NW == 0, "requests per wave");
   static_assert(HR * RP4 <= STAGE4, "stage size");
@@ -101,10 +106,20 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     bx = nl / nby;
     by = nl - bx * nby;
   }
+  // Chained tiles (W2D_F_CHAIN): this workgroup owns the pixel tiles [g0, g0 + nt) of the launch, nt <= p.chain, one after the other.
+  // What a tile costs beside its K loop is mostly WAITING - 7 000 (one workgroup per CU) to 17 000 (two) cycles between kernel entry and
+  // the first MFMA, 4 ms of a 31 ms forward (profiles/r06_w2d_idle_budget.md) - so the next tile's first super-chunks and weight slabs
+  // are requested by the ordinary in-loop DMA / weight stream of the current tile (the cursor simply runs on: no burst in front of
+  // the epilogue, which is what sank round 4's attempt), land during its last chunks and its epilogue, and the next K loop starts
+  // right behind the epilogue.  The exchange buffers then cannot overlay the stages: they lie behind them.
   const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
-  const int img = bx / (ntx * nty);
-  const int trem = bx - img * (ntx * nty);
-  const int y0 = (trem / ntx) * TH, x0 = (trem % ntx) * PXW;
+  const int tpi = ntx * nty;                                    // tiles per image
+  const int chain = CHAIN ? (p.chain > 1 ? p.chain : 1) : 1;
+  const int g0 = bx * chain;
+  const int nt = CHAIN ? min(chain, p.NB * tpi - g0) : 1;       // tiles of this workgroup
+  int img = g0 / tpi;
+  int y0 = ((g0 - img * tpi) / ntx) * TH, x0 = ((g0 - img * tpi) % ntx) * PXW;   // the tile the MFMAs / the epilogue are at
+  int c_t = 0, c_img = img, c_y0 = y0, c_x0 = x0;               // the tile the DMA cursor is at
   const int n0 = by * BN;
 
   auto uniform_ptr = [](const float* q) -> const float* {
@@ -121,8 +136,11 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // segment: (pixel offset from the first halo row) << 2 | piece, or ~0 for padding / outside ('same' padding = zeros), once per
   // workgroup - the three divisions per request used to be redone for every segment set-up, inlined at four places (a third of the
   // 1 190 instructions in front of the first MFMA; two waves per SIMD issue those at ~8 cycles each: the prologue is issue bound).
+  // Chained tiles: the tile-INDEPENDENT part of it (halo row | pixel << 8 | piece << 16 | slot in use << 31) is kept instead, and a tile /
+  // segment set-up forms the offsets from it and the cursor's tile - behind an opaque copy, or hipcc hoists the unpacked fields out
+  // of the tile loop (18 registers, spilled, reloaded with s_waitcnt vmcnt(0) in the middle of the K loop).
   unsigned rpk[IPW];
-  {
+  auto set_rpk = [&]() {   // for the cursor's tile (chained: tile independent, called once)
     const int H = p.H, W = p.W;
 #pragma unroll
     for (int n = 0; n < IPW; ++n) {
@@ -131,22 +149,39 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       const int m = rem / MO4, rr = rem - m * MO4;
       const int c = rr / CO4, k = rr - c * CO4;
       const int px = 4 * k + m;
-      const int y = y0 - 1 + r, x = x0 - 1 + px;
-      const bool ok = r < HR && rem < 4 * MO4 && px < PW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;   // else padding / outside the image
-      rpk[n] = ok ? (unsigned)(r * W + x) << 2 | (unsigned)c : OOB;
+      if constexpr (CHAIN) {
+        rpk[n] = (unsigned)r | (unsigned)px << 8 | (unsigned)c << 16 | ((r < HR && rem < 4 * MO4 && px < PW) ? 0x80000000u : 0u);
+      } else {
+        const int y = c_y0 - 1 + r, x = c_x0 - 1 + px;
+        const bool ok = r < HR && rem < 4 * MO4 && px < PW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;   // else padding / outside the image
+        rpk[n] = ok ? (unsigned)(r * W + x) << 2 | (unsigned)c : OOB;
+      }
     }
-  }
+  };
+  set_rpk();
   auto raw_setup_seg = [&]() {
     const ConvSeg& s = p.seg[rsg];
     rsegC = __builtin_amdgcn_readfirstlane(s.C);
-    int be = img + s.boff;
+    int be = c_img + s.boff;
     if (s.bmod && be >= s.bmod) be -= s.bmod;
     // (the finished pointer through readfirstlane: should hipcc ever reload `p` with vector loads - it does behind an atomic - a buffer
     // resource in VGPRs cannot feed the DMA statement - nor a buffer load without a waterfall loop)
-    rrsrc = conv_make_rsrc(uniform_ptr(s.ptr + ((long long)be * p.H + (y0 - 1)) * p.W * s.stride));
+    rrsrc = conv_make_rsrc(uniform_ptr(s.ptr + ((long long)be * p.H + (c_y0 - 1)) * p.W * s.stride));
     const unsigned st4 = (unsigned)s.stride * 4u;
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int n = 0; n < IPW; ++n) rvoff[n] = rpk[n] == OOB ? OOB : (rpk[n] >> 2) * st4 + (rpk[n] & 3u) * 16u;
+      for (int n = 0; n < IPW; ++n) {
+        unsigned ri = rpk[n];
+        asm volatile("" : "+v"(ri));
+        const int r = (int)(ri & 255u), px = (int)((ri >> 8) & 255u);
+        const int y = c_y0 - 1 + r, x = c_x0 - 1 + px;
+        const bool ok = (int)ri < 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+        rvoff[n] = ok ? (unsigned)(r * p.W + x) * st4 + ((ri >> 16) & 3u) * 16u : OOB;
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < IPW; ++n) rvoff[n] = rpk[n] == OOB ? OOB : (rpk[n] >> 2) * st4 + (rpk[n] & 3u) * 16u;
+    }
   };
   auto dma_piece = [&](int n, int stage) {   // request n of this wave's share of the cursor's super-chunk -> stage
     const unsigned so = (unsigned)rc0 * 4u;
@@ -156,7 +191,20 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   };
   auto dma_advance = [&]() {   // the cursor moves to the next super-chunk (16 channels), into the next input segment behind the last one
     rc0 += 16;
-    if (rc0 >= rsegC && rsg + 1 < p.nseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
+    if (rc0 >= rsegC) {
+      if (rsg + 1 < p.nseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
+      else if constexpr (CHAIN) {   // ... and into the next tile of the chain behind the last segment (a uniform branch, once per tile)
+        if (c_t + 1 < nt) {
+          ++c_t;
+          const int g = g0 + c_t;
+          c_img = g / tpi;
+          const int tr = g - c_img * tpi;
+          c_y0 = (tr / ntx) * TH; c_x0 = (tr % ntx) * PXW;
+          rc0 = 0; rsg = 0;
+          raw_setup_seg();
+        }
+      }
+    }
   };
   // split-K (ConvParams::ksplit, film_kernels.h; round 5): blockIdx.z = split z sums the super-chunks [sc0, sc1) of the K loop and
   // writes RAW partial sums to part[z][pixel][Cout]; conv_splitk_reduce_kernel adds them in split order with the bias and the
@@ -186,7 +234,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const conv_rsrc_t brsrc = conv_make_rsrc(uniform_ptr(p.w));
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const int ct = n0 / 32 + ng;
-  auto slab = [&](int kc) { return (unsigned)(((ct * nkc + (kc < nkc ? kc : nkc - 1)) * 4 + mu) * 6) * 1024u; };
+  // (past the end of the K range: a chained workgroup wraps to the first chunks - the next tile's; otherwise the last chunk again, unused)
+  auto slab = [&](int kc) { return (unsigned)(((ct * nkc + (CHAIN ? (kc < nkc ? kc : kc - nkc) : (kc < nkc ? kc : nkc - 1))) * 4 + mu) * 6) * 1024u; };
   bf4 fbg[2][6];
 
   f32x16 acc[6];
@@ -300,18 +349,29 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 #pragma unroll
   for (int j = 0; j < 6; ++j) fbg[1][j] = conv_buf_load(brsrc, bvoff, slab(kc0 + 1) + (unsigned)j * 1024u);
   __builtin_amdgcn_sched_barrier(0);
-  if (nsc > 1) raw_issue(1);
-  if (nsc > 2) raw_issue(2);
+  const int gtot = CHAIN ? nt * nsc : nsc;   // super-chunks of this workgroup (all its tiles)
+  if (gtot > 1) raw_issue(1);
+  if constexpr (NS > 2) { if (gtot > 2) raw_issue(2); }
   prepare(A[0], 0, C0{});
 
   // ---- K loop: chunk kc = (super-chunk s, half h).  Super-chunk s lives in stage s % 3; chunk kc prepares the fragments of chunk
   // kc + 1 while its own MFMAs run.  The barrier at the top of chunk (s, 1) publishes super-chunk s + 1 (first read right behind it)
   // and says that nobody reads stage s % 3 any more: super-chunk s + 3 goes there, its requests in gaps of chunks (s, 1), (s + 1, 0).
+  // Two stages (NS = 2): super-chunk s + 2 goes to stage s % 2, ALL its requests in gaps of chunk (s, 1) - it then has chunk (s + 1, 0)
+  // to land in, and the six weight requests of that chunk are younger than it (the vmcnt below).
   int st_s = 0, st_n = 1;    // stages of super-chunks s and s + 1
   int st_dma = 0;            // stage of the super-chunk whose requests are being issued
   bool dma_on = false;
-  constexpr int P1 = (IPW + 1) / 2, P0 = IPW - P1;   // requests issued in the gaps of chunk (s, 1) / of chunk (s + 1, 0)
-  static_assert(P0 > 0, "the cursor advances behind the last request of chunk (s + 1, 0)");
+  int gs = 0;                // super-chunks this workgroup has finished (over all its tiles)
+  constexpr int P1 = NS == 2 ? IPW : (IPW + 1) / 2, P0 = IPW - P1;   // requests issued in the gaps of chunk (s, 1) / of chunk (s + 1, 0)
+  // request index a gap carries (-1: none) when a chunk issues CNT of them: 1 -> gap 13; 2 -> 5, 17; 3 -> 5, 13, 21; 6 -> 2, 5, 9, 13, 17, 21
+  // (never gaps 0 / 1: the fragment reads)
+  auto dma_slot = [](int g, int cnt) constexpr -> int {
+    if (cnt <= 0) return -1;
+    if (cnt == 6) return g == 2 ? 0 : (g >= 5 && (g - 5) % 4 == 0) ? 1 + (g - 5) / 4 : -1;
+    const int step = 24 / cnt, at = cnt == 1 ? 13 : 5;
+    return (g % step == at && g / step < cnt) ? g / step : -1;
+  };
   auto chunk = [&](int kc, auto h_c) {
     constexpr int H = decltype(h_c)::value;
     using RH = std::integral_constant<int, 1 - H>;
@@ -326,12 +386,12 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tw0 = __builtin_readcyclecounter();
       if constexpr ((FLAGS & W2D_DBG_NOB) != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       else {
-        if (kc == kc0 + 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (NS == 2 || gs == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
       }
       if constexpr ((FLAGS & W2D_DBG_NOBAR) == 0) __syncthreads();
       if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmW += __builtin_readcyclecounter() - tw0;   // s_waitcnt + barrier of this super-chunk
-      dma_on = (kc >> 1) + NS < sc1;
+      dma_on = CHAIN ? gs + NS < gtot : (kc >> 1) + NS < sc1;
       st_dma = st_s;
     }
     const unsigned so2 = slab(kc + 2);
@@ -401,11 +461,11 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       }
       if constexpr ((FLAGS & W2D_DBG_NODMA) == 0) {   // a DMA request in a gap without fragment reads
         constexpr int CNT = H == 1 ? P1 : P0, N0 = H == 1 ? 0 : P1;
-        constexpr int step = 24 / CNT;
-        if constexpr (g % step == (CNT == 1 ? 13 : 5) && g / step < CNT) {
+        constexpr int idx = dma_slot(g, CNT);
+        if constexpr (idx >= 0) {
           if (dma_on) {
-            dma_piece(N0 + g / step, st_dma);
-            if constexpr (H == 0 && g / step == CNT - 1) dma_advance();
+            dma_piece(N0 + idx, st_dma);
+            if constexpr (N0 + idx == IPW - 1) dma_advance();   // behind the super-chunk's last request
           }
         }
       }
@@ -415,14 +475,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     if constexpr (H == 1) {
       st_s = st_n;
       st_n = st_n + 1 == NS ? 0 : st_n + 1;
+      ++gs;
     }
   };
-  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm1 = __builtin_readcyclecounter();
-  for (int kc = kc0; kc < kc1; kc += 2) {
-    chunk(kc, C0{});
-    chunk(kc + 1, C1{});
-  }
-  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm2 = __builtin_readcyclecounter();
 
   // ---- epilogue.  C/D layout of the 32x32 MFMA with A = weights: column = lane & 31 = unit, row = (r&3) + 8*(r>>2) + 4*(lane>>5) =
   // output channel of the wave's 32.  x inverse in registers (per mu plane; conv_wino2d_r3_kernel's sums: the products by 2, 4, 8 are
@@ -430,105 +485,145 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // [unit][32 channels] (16-byte pieces swizzled by the unit: conflict-free both ways), barrier, thread (unit, 4-channel group)
   // reads the four mu planes and forms row 2k = (m0 + m1) + m2 and row 2k + 1 = (m1 - m2) - m3 (conv_wino2d_r3_kernel's), bias,
   // leaky_relu, two dwordx4 stores.  Two exchange buffers: the writes of round jx + 1 do not wait for the readers of round jx.
-  __syncthreads();   // the exchange buffers overlay the stages (the last chunk prepared fragments nobody uses: its reads are done)
-  float o[4][16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
-    const float s34 = m3 + m4, d34 = m3 - m4, d12 = m1 - m2, s12 = m1 + m2;
-    o[0][r] = ((m0 + m1) + m2) + s34;
-    o[1][r] = __builtin_fmaf(2.f, d34, d12);
-    o[2][r] = __builtin_fmaf(4.f, s34, s12);
-    o[3][r] = d12 + __builtin_fmaf(8.f, d34, m5);
-  }
-  bf4* const xb = reinterpret_cast<bf4*>(smem);   // [buffer 2][ng][mu][unit 32][piece 8] float4
-  constexpr int XB4 = NG * 4 * 256;
-  static_assert(2 * XB4 <= NS * STAGE4, "exchange buffers");
-  const int widx = (ng * 4 + mu) * 256 + l31 * 8;   // + ((2 g + half) ^ (unit & 7))
-  const int rng = t >> 8, run = (t >> 3) & 31, rcg = t & 7;   // reader: channel tile, unit, 4-channel group
-  const int ridx = rng * 1024 + run * 8 + (rcg ^ (run & 7));  // + mu * 256
-  const int nrd = n0 + rng * 32 + rcg * 4;
-  const bool rawsum = ksp > 1;   // split-K: no bias, no activation, [split][pixel][Cout]
-  const float b0 = rawsum ? 0.f : p.bias[nrd], b1 = rawsum ? 0.f : p.bias[nrd + 1], b2 = rawsum ? 0.f : p.bias[nrd + 2], b3 = rawsum ? 0.f : p.bias[nrd + 3];
-  const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
-  const int ostr = rawsum ? p.Cout : p.ostride;
-  const bool act = p.leaky && !rawsum;
-  float* const orow = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + oy) * p.W + ox) * ostr + nrd;
-  // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
-  // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
-  // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][68] behind the exchange
-  // buffers instead of to `out` (68: 16-byte rows whose float4 pieces fall into 16 different bank groups for 16 consecutive pixels -
-  // conflict-free ds_write_b128 from the (unit, channel group) threads and ds_read_b128 from the pixel threads); the 1x1 weights go
-  // to LDS once as [c][4]; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
-  float* const pool_base = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.pool_ostride + nrd : nullptr;
-  constexpr int PWS = 68;
-  float* const pwt = smem + 2 * XB4 * 4;
-  float* const pww = pwt + TH * PXW * PWS;   // [64][4]
-  if (p.pw_out != nullptr && t < 256) pww[t] = (t & 3) < p.pw_cout ? p.pw_w[(t >> 2) * p.pw_cout + (t & 3)] : 0.f;   // (published by the rounds' barriers)
-  bf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int jx = 0; jx < 4; ++jx) {
-    bf4* const xw = xb + (jx & 1) * XB4;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      bf4 v;
-      v[0] = o[jx][4 * g]; v[1] = o[jx][4 * g + 1]; v[2] = o[jx][4 * g + 2]; v[3] = o[jx][4 * g + 3];
-      xw[widx + ((2 * g + half) ^ (l31 & 7))] = v;
+  auto epilogue = [&]() {
+    // (chained: everything below that depends only on the thread index is loop invariant over the tiles, and hipcc hoists it out of the tile
+    // loop - index registers, bias values and pointer bases then live through the K loop, which spilled.  An opaque copy of the thread
+    // index keeps the epilogue's values inside the epilogue.)
+    int te = (int)threadIdx.x;
+    if constexpr (CHAIN) asm volatile("" : "+v"(te));
+    const int t = te, lane = t & 63, l31 = lane & 31, half = lane >> 5;
+    if constexpr (!CHAIN) __syncthreads();   // the exchange buffers overlay the stages (the last chunk prepared fragments nobody uses: its reads are done)
+                                             // (chained: they lie behind the stages, which already hold the next tile's first super-chunks; a buffer's
+                                             // next writers - round jx of the NEXT tile - are a whole K loop of barriers behind its last readers)
+    float o[4][16];
+  #pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float m0 = acc[0][r], m1 = acc[1][r], m2 = acc[2][r], m3 = acc[3][r], m4 = acc[4][r], m5 = acc[5][r];
+      const float s34 = m3 + m4, d34 = m3 - m4, d12 = m1 - m2, s12 = m1 + m2;
+      o[0][r] = ((m0 + m1) + m2) + s34;
+      o[1][r] = __builtin_fmaf(2.f, d34, d12);
+      o[2][r] = __builtin_fmaf(4.f, s34, s12);
+      o[3][r] = d12 + __builtin_fmaf(8.f, d34, m5);
     }
-    __syncthreads();
-    const bf4 m0 = xw[ridx], m1 = xw[ridx + 256], m2 = xw[ridx + 512], m3 = xw[ridx + 768];
-    bf4 r0, r1;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
-      float v0 = ((m0[c] + m1[c]) + m2[c]) + bv, v1 = ((m1[c] - m2[c]) - m3[c]) + bv;
-      if (act) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
-      r0[c] = v0; r1[c] = v1;
-    }
-    if (p.pw_out == nullptr) {
-      if (ox + jx < p.W) {
-        float* const o0 = orow + (size_t)jx * ostr;
-        if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
-        if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * ostr) = r1;
+    bf4* const xb = reinterpret_cast<bf4*>(smem) + (CHAIN ? NS * STAGE4 : 0);   // [buffer 2][ng][mu][unit 32][piece 8] float4
+    constexpr int XB4 = NG * 4 * 256;
+    static_assert(CHAIN || 2 * XB4 <= NS * STAGE4, "exchange buffers");
+    const int widx = (ng * 4 + mu) * 256 + l31 * 8;   // + ((2 g + half) ^ (unit & 7))
+    const int rng = t >> 8, run = (t >> 3) & 31, rcg = t & 7;   // reader: channel tile, unit, 4-channel group
+    const int ridx = rng * 1024 + run * 8 + (rcg ^ (run & 7));  // + mu * 256
+    const int nrd = n0 + rng * 32 + rcg * 4;
+    const bool rawsum = ksp > 1;   // split-K: no bias, no activation, [split][pixel][Cout]
+    const float b0 = rawsum ? 0.f : p.bias[nrd], b1 = rawsum ? 0.f : p.bias[nrd + 1], b2 = rawsum ? 0.f : p.bias[nrd + 2], b3 = rawsum ? 0.f : p.bias[nrd + 3];
+    const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
+    const int ostr = rawsum ? p.Cout : p.ostride;
+    const bool act = p.leaky && !rawsum;
+    float* const orow = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + oy) * p.W + ox) * ostr + nrd;
+    // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
+    // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
+    // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][68] behind the exchange
+    // buffers instead of to `out` (68: 16-byte rows whose float4 pieces fall into 16 different bank groups for 16 consecutive pixels -
+    // conflict-free ds_write_b128 from the (unit, channel group) threads and ds_read_b128 from the pixel threads); the 1x1 weights go
+    // to LDS once as [c][4]; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
+    float* const pool_base = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.pool_ostride + nrd : nullptr;
+    constexpr int PWS = 68;
+    float* const pwt = smem + 2 * XB4 * 4;   // (never with W2D_F_CHAIN: the launcher refuses the fused 1x1 there)
+    float* const pww = pwt + TH * PXW * PWS;   // [64][4]
+    if (p.pw_out != nullptr && t < 256) pww[t] = (t & 3) < p.pw_cout ? p.pw_w[(t >> 2) * p.pw_cout + (t & 3)] : 0.f;   // (published by the rounds' barriers)
+    bf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+      bf4* const xw = xb + (jx & 1) * XB4;
+  #pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf4 v;
+        v[0] = o[jx][4 * g]; v[1] = o[jx][4 * g + 1]; v[2] = o[jx][4 * g + 2]; v[3] = o[jx][4 * g + 3];
+        xw[widx + ((2 * g + half) ^ (l31 & 7))] = v;
       }
-      if (pool_base != nullptr) {
-        if (jx & 1) {
-          bf4 pv;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) pv[c] = (((k0[c] + r0[c]) + k1[c]) + r1[c]) * 0.25f;
-          if (oy < p.H && ox + jx < p.W) *reinterpret_cast<bf4*>(pool_base + (size_t)(jx >> 1) * p.pool_ostride) = pv;
-        } else {
-          k0 = r0; k1 = r1;
+      __syncthreads();
+      const bf4 m0 = xw[ridx], m1 = xw[ridx + 256], m2 = xw[ridx + 512], m3 = xw[ridx + 768];
+      bf4 r0, r1;
+  #pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
+        float v0 = ((m0[c] + m1[c]) + m2[c]) + bv, v1 = ((m1[c] - m2[c]) - m3[c]) + bv;
+        if (act) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
+        r0[c] = v0; r1[c] = v1;
+      }
+      if (p.pw_out == nullptr) {
+        if (ox + jx < p.W) {
+          float* const o0 = orow + (size_t)jx * ostr;
+          if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
+          if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * ostr) = r1;
+        }
+        if (pool_base != nullptr) {
+          if (jx & 1) {
+            bf4 pv;
+  #pragma unroll
+            for (int c = 0; c < 4; ++c) pv[c] = (((k0[c] + r0[c]) + k1[c]) + r1[c]) * 0.25f;
+            if (oy < p.H && ox + jx < p.W) *reinterpret_cast<bf4*>(pool_base + (size_t)(jx >> 1) * p.pool_ostride) = pv;
+          } else {
+            k0 = r0; k1 = r1;
+          }
+        }
+      } else {
+        float* const tr = pwt + ((2 * (run >> 3)) * PXW + 4 * (run & 7) + jx) * PWS + rng * 32 + rcg * 4;
+        *reinterpret_cast<bf4*>(tr) = r0;
+        *reinterpret_cast<bf4*>(tr + PXW * PWS) = r1;
+      }
+    }
+    if (p.pw_out != nullptr) {
+      __syncthreads();
+      if (t < TH * PXW) {
+        const int y = y0 + t / PXW, x = x0 + (t % PXW);
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        const bf4* row = reinterpret_cast<const bf4*>(pwt + t * PWS);
+        const bf4* wq = reinterpret_cast<const bf4*>(pww);
+  #pragma unroll 4
+        for (int c4 = 0; c4 < 16; ++c4) {
+          const bf4 v = row[c4];
+  #pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const bf4 w = wq[c4 * 4 + k];
+  #pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = __builtin_fmaf(v[k], w[j], a[j]);   // (columns past pw_cout: zero weights, never stored)
+          }
+        }
+        if (y < p.H && x < p.W) {
+          float* dd = p.pw_out + (((size_t)img * p.H + y) * p.W + x) * p.pw_ostride;
+  #pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (j < p.pw_cout) dd[j] = a[j] + p.pw_bias[j];
         }
       }
-    } else {
-      float* const tr = pwt + ((2 * (run >> 3)) * PXW + 4 * (run & 7) + jx) * PWS + rng * 32 + rcg * 4;
-      *reinterpret_cast<bf4*>(tr) = r0;
-      *reinterpret_cast<bf4*>(tr + PXW * PWS) = r1;
     }
-  }
-  if (p.pw_out != nullptr) {
-    __syncthreads();
-    if (t < TH * PXW) {
-      const int y = y0 + t / PXW, x = x0 + (t % PXW);
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      const bf4* row = reinterpret_cast<const bf4*>(pwt + t * PWS);
-      const bf4* wq = reinterpret_cast<const bf4*>(pww);
-#pragma unroll 4
-      for (int c4 = 0; c4 < 16; ++c4) {
-        const bf4 v = row[c4];
+  };
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tm1 = __builtin_readcyclecounter();
+  for (int ti = 0; ti < nt; ++ti) {
+    if (ti > 0) {   // the next tile of the chain: its first super-chunks are in the stages, its first two weight slabs in fbg, the
+                    // fragments of its chunk 0 in A[0] (prepared by the last chunk of the tile before, like any chunk kc + 1)
+      const int g = g0 + ti;
+      img = g / tpi;
+      const int tr = g - img * tpi;
+      y0 = (tr / ntx) * TH; x0 = (tr % ntx) * PXW;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const bf4 w = wq[c4 * 4 + k];
+      for (int v = 0; v < 6; ++v)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a[j] = __builtin_fmaf(v[k], w[j], a[j]);   // (columns past pw_cout: zero weights, never stored)
-        }
-      }
-      if (y < p.H && x < p.W) {
-        float* dd = p.pw_out + (((size_t)img * p.H + y) * p.W + x) * p.pw_ostride;
+        for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+    }
+    for (int kc = kc0; kc < kc1; kc += 2) {
+      chunk(kc, C0{});
+      chunk(kc + 1, C1{});
+    }
+    if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { if (ti + 1 == nt) tm2 = __builtin_readcyclecounter(); }
+    epilogue();
+    if constexpr (CHAIN) {
+      if (ti + 1 < nt) {
+        // Only the next tile's FIRST weight slab (fbg[0], requested by this tile's second-to-last chunk) lives through the epilogue: the second
+        // one and the fragments of its chunk 0 are formed again here - 48 registers the epilogue needs (it spilled with them alive).
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (j < p.pw_cout) dd[j] = a[j] + p.pw_bias[j];
+        for (int j = 0; j < 6; ++j) fbg[1][j] = conv_buf_load(brsrc, bvoff, slab(kc0 + 1) + (unsigned)j * 1024u);
+        __builtin_amdgcn_sched_barrier(0);
+        prepare(A[0], st_s, C0{});
       }
     }
   }
@@ -545,12 +640,16 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   }
 }
 
-template <int BN, int FLAGS>
+template <int BN, int FLAGS, int NS = 3>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
-  // three stages; the exchange buffers (2 x BN / 32 x 16 KB) fit inside; the fused 1x1 adds its [256][68] tile and its weights behind them
-  const size_t lds = p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024 : (size_t)3 * 24 * 1024;
+  constexpr bool CHAIN = (FLAGS & W2D_F_CHAIN) != 0;
+  // NS stages of 24 KB; the exchange buffers (2 x BN / 32 x 16 KB) fit inside them - or, chained, lie behind them (80 KB for the 32-channel
+  // tile on two stages: two workgroups per CU; 136 KB for the 64-channel one); the fused 1x1 adds its [256][68] tile and its weights
+  const size_t lds = CHAIN ? (size_t)NS * 24 * 1024 + (size_t)2 * (BN / 32) * 16 * 1024
+                           : p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024 : (size_t)NS * 24 * 1024;
   constexpr int NT = 4 * (BN / 32) * 64;
   if (p.ksize != 3 || p.Ctot % 16 || p.Cout % BN) return hipErrorInvalidValue;
+  if (CHAIN && (p.ksplit > 1 || p.pw_out || p.chain < 1)) return hipErrorInvalidValue;
   if (p.ksplit > 1 && (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) || p.Cout % 4 || p.pool_out || p.pw_out || p.ksplit > p.Ctot / 16)) return hipErrorInvalidValue;
   if (p.pw_out) {   // a workgroup must hold every channel of its pixels
     if (BN != 64 || p.Cout != 64 || p.pool_out || p.pw_cout < 1 || p.pw_cout > 4) return hipErrorInvalidValue;
@@ -558,11 +657,12 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   if (p.pool_out && ((p.H | p.W) & 1 || p.pool_ostride % 4 || (reinterpret_cast<uintptr_t>(p.pool_out) & 15))) return hipErrorInvalidValue;
   for (int i = 0; i < p.nseg; ++i)
     if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
-  auto kern = conv_wino2d_kernel<BN, FLAGS>;
+  auto kern = conv_wino2d_kernel<BN, FLAGS, NS>;
   static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
   if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, 144 * 1024); e != hipSuccess) return e;
   const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
-  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
+  const int ntiles = p.NB * ntx * nty, chain = CHAIN ? p.chain : 1;
+  dim3 grid((unsigned)((ntiles + chain - 1) / chain), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
   return hipGetLastError();
 }

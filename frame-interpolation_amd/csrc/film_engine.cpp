@@ -145,7 +145,10 @@ inline int w43_tile(int sh) { return (sh & 15) | (sh >= 16 ? CONV_TILE_EXT : 0) 
 std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false) {
   if (pw) {   // the fused 1x1 needs every channel of a pixel in one workgroup: the NH = 1 tiles at Cout = 64
     std::vector<int> out;
-    for (int sh : {W43_Q16_4x64_N1, W43_Q16_4x64_N1_P2, W43_Q8_8x64_N1_P2}) { out.push_back(w43_tile(sh)); out.push_back(w43_tile(sh) | CONV_TILE_XCD); }
+    for (int sh : {W43_Q16_4x64_N1, W43_Q16_4x64_N1_P2, W43_Q8_8x64_N1_P2}) {
+      if (!film_w43_shape_built(sh)) continue;
+      out.push_back(w43_tile(sh)); out.push_back(w43_tile(sh) | CONV_TILE_XCD);
+    }
     return out;
   }
   // the 64-pixel ("Q16", two workgroups per CU) tiles won every layer of the 1080p plan against the 128-pixel ones
@@ -158,6 +161,7 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
                                             : std::vector<int>{W43_4x32_T11, W43_Q16_4x32_T11, W43_Q16_4x32_T11_P2, W43_Q16_4x32_T11_BG, W43_Q8_8x32_T11_BG, W43_Q8_8x32_T11_P2};
   std::vector<int> out;
   for (int sh : shapes) {
+    if (!film_w43_shape_built(sh)) continue;   // (the default library holds seven of the seventeen tiles)
     if (pool && (sh == W43_4x64_T21 || sh == W43_4x64_T12 || sh == W43_4x32_T11)) continue;   // the fused pool needs a <= 64-pixel tile
     out.push_back(w43_tile(sh)); out.push_back(w43_tile(sh) | CONV_TILE_XCD);
   }
@@ -166,7 +170,7 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
 
 std::vector<int> wino2d_candidates(int Cout, bool pw = false) {
   std::vector<int> out;
-  for (int sh : (pw ? std::vector<int>{W2D_8x64} /* the fused 1x1 needs every channel of a pixel in one workgroup */ : Cout % 64 == 0 ? std::vector<int>{W2D_8x64, W2D_8x32} : std::vector<int>{W2D_8x32})) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
+  for (int sh : (pw ? std::vector<int>{W2D_8x64} /* the fused 1x1 needs every channel of a pixel in one workgroup */ : Cout % 64 == 0 ? std::vector<int>{W2D_8x64, W2D_8x32, W2D_8x32_S2} : std::vector<int>{W2D_8x32, W2D_8x32_S2})) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
   return out;
 }
 

@@ -59,6 +59,8 @@ struct ConvParams {
   // K loop (up to 1080 steps) otherwise runs on a handful of workgroups.
   int ksplit;
   float* part;
+  // conv_wino2d_kernel with W2D_F_CHAIN: consecutive pixel tiles one workgroup walks (>= 1; conv_wino2d_impl.h, "chained tiles")
+  int chain;
   // Fused AveragePooling2D(2, 2) of the output (feature_extractor.py:138-146: every sub-extractor stage but the last
   // is followed by a pool), conv_wino43_kernel's 64-pixel tiles only: the epilogue also writes
   // pool_out[img][y/2][x/2][n] = (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25 (pool_vec_kernel's order) from
@@ -229,9 +231,20 @@ enum Wino43Tile { W43_4x64_T21 = 0, W43_4x64_T12 = 1, W43_4x32_T11 = 2, W43_Q16_
                   /* ids >= 16 carry CONV_TILE_EXT in the tile id (shape = (tile & 15) + 16).  The 32-channel Q8 tile WITH the
                      weight ring: 48 KB of LDS, 152 VGPRs -> three workgroups per CU (flow level 0 conv_0: -7 % against the BG tile) */
                   W43_Q8_8x32_T11_P2 = 16 };
+// the Wino43Tile shapes this build of the library instantiates (conv_igemm.hip): all of them with FILM_EXTRA_FAMILIES, seven without
+static inline bool film_w43_shape_built(int sh) {
+#ifdef FILM_EXTRA_FAMILIES
+  return sh >= 0 && sh <= W43_Q8_8x32_T11_P2;
+#else
+  return sh == W43_Q16_4x64_T21_P2 || sh == W43_Q16_4x32_T11_P2 || sh == W43_Q16_4x64_N1_P2 || sh == W43_Q8_8x64_T21_P2 || sh == W43_Q8_8x64_N1_P2 ||
+         sh == W43_Q8_8x32_T11_BG || sh == W43_Q8_8x32_T11_P2;
+#endif
+}
 // conv_wino2d_kernel tiles (CONV_TILE_W2D): one 32-unit MFMA tile (unit = 2 rows x 4 pixels; 8 rows x 32 pixels) x output channels;
 // 64 channels = 8 waves (one workgroup per CU), 32 channels = 4 waves (two per CU).  Same sums: the autotuner picks freely.
-enum Wino2dTile { W2D_8x64 = 0, W2D_8x32 = 1, W2D_SHAPES = 2 };
+// W2D_8x32_S2 (round 6): the 32-channel tile on TWO DMA stages instead of three (48 KB of LDS; all requests of a super-chunk in the gaps of ONE
+// chunk, one super-chunk less requested in the prologue): 4-15 % faster on every layer with K <= 208, equal above (profiles/r06_w2d_chain_ns2.log).
+enum Wino2dTile { W2D_8x64 = 0, W2D_8x32 = 1, W2D_8x32_S2 = 2, W2D_SHAPES = 3 };
 // conv_fold4_kernel tiles (CONV_TILE_FOLD4): 4 rows x 32 low-resolution pixels x output channels; four waves side by side, each 4 x 8 pixels
 // x all channels of the tile.  64 channels: 235 VGPRs, two workgroups per CU; 32 channels: 139 VGPRs, three.  Same sums.
 enum Fold4Tile { F4_4x64 = 0, F4_4x32 = 1 };

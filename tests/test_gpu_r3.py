@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import inputs as TI
+from conftest import prefers_extra_families
 from test_gpu_parity import _engine
 
 pytestmark = pytest.mark.gpu
@@ -149,6 +150,7 @@ def test_sharded_interpolator_and_tile_gather_over_rccl(published, tmp_path):
 # ---------------------------------------------------------------------------------------------------------------------
 # weights: second set on a used engine, SavedModel directory
 # ---------------------------------------------------------------------------------------------------------------------
+@prefers_extra_families
 def test_second_weight_set_on_a_used_engine(tiny_weights):
     """forward -> set_weights(other set) -> forward of the SAME shape on the SAME handle (cached plan, layout groups the
     plan pulled in on demand) == a fresh engine that only ever saw the second set (round-2 ADVICE: the re-finalize used
@@ -288,6 +290,7 @@ def test_parity_with_flows_that_leave_the_frame_at_every_level():
 # ---------------------------------------------------------------------------------------------------------------------
 # conv_wino43_kernel: every tile shape (incl. the round-3 32-pixel x 8-row "Q8" tiles) gives the same bits
 # ---------------------------------------------------------------------------------------------------------------------
+@prefers_extra_families      # (the default library holds seven of the seventeen tiles, the extra flavour all of them)
 @pytest.mark.parametrize('b,h,w', [(1, 128, 320), (2, 192, 256), (1, 64, 960)])
 def test_every_f43_tile_shape_gives_the_same_bits(published, b, h, w):
     """F(4,3) forced onto every eligible 3x3 layer ("winograd" = 3), then every Wino43Tile shape forced in turn ("w43_shape"):
@@ -367,7 +370,7 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
     got, _ = _check_stages(eng, opt, wts, x0, x1)
     taps = {k: eng.tap(k) for k in ('feat1', 'aligned0', 'aligned1')}
     used = set()
-    for shape in range(2):        # Wino2dTile: 0 = 64 channels per workgroup (8 waves), 1 = 32 (4 waves, two workgroups per CU)
+    for shape in range(3):        # Wino2dTile: 0 = 64 channels per workgroup (8 waves), 1 = 32 (4 waves, two workgroups per CU), 2 = 32 on two DMA stages
         eng.set_option('w2d_shape', shape)
         tiles = {o['tile'] & 15 for o in eng.plan(b, h, w)['ops'] if o['kind'] == 'conv_mfma' and (o['tile'] & 8192)}
         if shape not in tiles:
@@ -378,7 +381,7 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
         for k, v in taps.items():
             assert np.array_equal(eng.tap(k), v), (shape, k)
     print('nested-Winograd tile shapes exercised:', sorted(used))
-    assert {0, 1} <= used, used
+    assert {0, 1, 2} <= used, used
     eng.set_option('w2d_shape', -1)
     eng.set_option('wino2d', 0)
     assert sum(1 for op in eng.plan(b, h, w)['ops'] if op.get('wino') == 4) == 0

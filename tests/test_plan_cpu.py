@@ -12,7 +12,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import oracle_options, ROOT
+from conftest import oracle_options, prefers_extra_families, ROOT
 
 
 def test_library_exports_every_declared_symbol():
@@ -237,6 +237,7 @@ def test_plan_interpreter_matches_oracle_published_64(published_packed):
     assert np.array_equal(pi.tap(plan3, arena3, 'out'), pi.tap(plan, arena, 'out'))
 
 
+@prefers_extra_families
 def test_precision_modes_choose_kernel_families_by_shape_only():
     """The kernel family of a layer is a pure function of (layer shape, precision option) - never of batch size or
     timing.  Mode 0: no split kernels, conv_wino43_kernel (wino = 3) / conv_wino_kernel (1) by level width; mode 1: conv_halo_split_kernel (split = 1); mode 2: conv_winox3_kernel
@@ -488,6 +489,7 @@ def test_tune_cache_text_round_trip_and_validation(tiny_weights):
     eng.close()
 
 
+@prefers_extra_families
 def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_weights):
     """A handle whose cached plans pulled in the on-demand layout groups (Planner::need_groups: F(2,3), halo copies) gets a
     SECOND weight set (film_finalize via set_weights / film_import_packed): every group that was packed before must be packed

@@ -132,6 +132,14 @@ static hipError_t w2d_split(const ConvParams& p0, hipStream_t st) {
   return hipGetLastError();
 }
 #define W2S(NAME, BN, S) {"w2d " NAME, BN, 3, w2d_split<BN, S>}
+// chained tiles (W2D_F_CHAIN): CH consecutive pixel tiles per workgroup, NS stages; the same sums as the unchained kernel
+template <int BN, int NS, int CH, int FL>
+static hipError_t w2d_chain(const ConvParams& p0, hipStream_t st) {
+  ConvParams p = p0;
+  p.chain = CH;
+  return conv_wino2d_launch<BN, 4 | W2D_F_CHAIN | FL, NS>(p, st);
+}
+#define W2C(NAME, BN, NS, CH) {"w2d " NAME, BN, 1, w2d_chain<BN, NS, CH, 0>}
 #define W43(NAME, BN, ...) {"w43 " NAME, BN, 2, conv_wino43_launch<__VA_ARGS__>}
 static Variant variants[] = {
     W43("q16 4x64 t21 p2", 64, 4, 64, 2, 1, 4 | W43_F_PF2, 16), W43("q16 4x64 n1 p2", 64, 4, 64, 1, 1, 4 | W43_F_PF2, 16, 1), W43("q8 8x64 t21 p2", 64, 8, 64, 2, 1, 4 | W43_F_PF2, 8),
@@ -139,7 +147,11 @@ static Variant variants[] = {
     W2N("64 xf", 64, 4 | W2D_F_XFIRST), W2N("32 xf", 32, 4 | W2D_F_XFIRST),
     W2N("64", 64, 4), W2N("32", 32, 4), W2N("64 plain", 64, 0), W2N("32 plain", 32, 0),
     W2S("64 split2", 64, 2), W2S("32 split2", 32, 2), W2S("64 split3", 64, 3), W2S("32 split3", 32, 3), W2S("64 split4", 64, 4), W2S("32 split4", 32, 4),
+    W2C("32 ns2 ch1", 32, 2, 1), W2C("32 ns2 ch2", 32, 2, 2), W2C("32 ns2 ch4", 32, 2, 4), W2C("32 ns2 ch8", 32, 2, 8),
+    W2C("64 ns3 ch1", 64, 3, 1), W2C("64 ns3 ch2", 64, 3, 2), W2C("64 ns3 ch4", 64, 3, 4), W2C("64 ns3 ch8", 64, 3, 8),
+    {"w2d 32 ns2 plain", 32, 1, conv_wino2d_launch<32, 4, 2>},
     W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
+    {"w2d 32 ns2 ch4 time", 32, -1, w2d_chain<32, 2, 4, W2D_DBG_TIME>}, {"w2d 64 ns3 ch4 time", 64, -1, w2d_chain<64, 3, 4, W2D_DBG_TIME>},
     W2N("64 abl-noxf", 64, 4 | W2D_DBG_NOXF), W2N("32 abl-noxf", 32, 4 | W2D_DBG_NOXF),
     W2N("64 abl-nodma", 64, 4 | W2D_DBG_NODMA), W2N("32 abl-nodma", 32, 4 | W2D_DBG_NODMA),
     W2N("64 abl-nob", 64, 4 | W2D_DBG_NOB), W2N("32 abl-nob", 32, 4 | W2D_DBG_NOB),
