@@ -100,7 +100,14 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
       rvoff[n] = ok ? (unsigned)(r * p.W + x) * st4 + (unsigned)c * 16u : OOB;
     }
   }
-  int rc0 = 0;   // first channel of the DMA cursor's super-chunk
+  // split-K (ConvParams::ksplit): blockIdx.z = split z sums the super-chunks [sc0, sc1) and writes RAW sums of the four output pixels to
+  // part[z][output pixel][Cout] (the outputs are linear in the four planes); conv_splitk_reduce_kernel adds them in split order with the bias.
+  // For the decoder's coarsest layer (36x60 low-resolution pixels, K = 1936: 1152 workgroups on 768 slots = 1.5 rounds of 0.3 ms).
+  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
+  const int nsc_all = p.Ctot >> 4;
+  const int sc0 = ksp > 1 ? (int)((unsigned)nsc_all * blockIdx.z / (unsigned)ksp) : 0;
+  const int sc1 = ksp > 1 ? (int)((unsigned)nsc_all * (blockIdx.z + 1u) / (unsigned)ksp) : nsc_all;
+  int rc0 = sc0 * 16;   // first channel of the DMA cursor's super-chunk
   auto dma_piece = [&](int n, int stage) {
     const unsigned so = (unsigned)rc0 * 4u;
     const unsigned base = lds0 + (unsigned)stage * (STAGE4 * 16u) + (unsigned)(wv + NW * n) * 1024u;
@@ -114,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
   };
 
   // ---- weights: [Cout / 32][chunk][plane 4][K half][32][4] floats; every wave of the workgroup reads the slabs of the NCT tiles -----
-  const int nkc = p.Ctot / 8, nsc = p.Ctot / 16;
+  const int nkc = p.Ctot / 8, nsc = sc1 - sc0, kc0 = 2 * sc0, kc1 = 2 * sc1;
   const conv_rsrc_t brsrc = conv_make_rsrc(uniform_ptr(p.w));
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const unsigned tstep = (unsigned)nkc * 4096u;   // bytes between two 32-channel tiles
@@ -160,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
   // ---- prologue (conv_wino2d_kernel's order: stage 0 and the first slab alone, the rest behind the stage-0 barrier) ---------------
   raw_issue(0);
 #pragma unroll
-  for (int j = 0; j < NB8; ++j) fb[j / NCT][j % NCT] = conv_buf_load(brsrc, bvoff, slab(0) + (unsigned)(j % NCT) * tstep + (unsigned)(j / NCT) * 1024u);
+  for (int j = 0; j < NB8; ++j) fb[j / NCT][j % NCT] = conv_buf_load(brsrc, bvoff, slab(kc0) + (unsigned)(j % NCT) * tstep + (unsigned)(j / NCT) * 1024u);
   __builtin_amdgcn_sched_barrier(0);
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB8) : "memory");   // this wave's share of stage 0 (older than the weight requests)
   __syncthreads();
@@ -188,11 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
       // front of the 2 NB8 weight requests of chunks kc - 2 and kc - 1 (in-order return); everybody else's are published by the barrier.
       unsigned long long tw0 = 0;
       if constexpr ((FLAGS & F4_DBG_TIME) != 0) tw0 = __builtin_readcyclecounter();
-      if (kc == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB8) : "memory");   // (stage 1: only chunk 0's weight requests are younger for sure)
+      if (kc == kc0 + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB8) : "memory");   // (stage 1: only chunk 0's weight requests are younger for sure)
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB8) : "memory");
       __syncthreads();
       if constexpr ((FLAGS & F4_DBG_TIME) != 0) tmW += __builtin_readcyclecounter() - tw0;
-      dma_on = (kc >> 1) + NS < nsc;
+      dma_on = (kc >> 1) + NS < sc1;
       st_dma = st_s;
     }
     const unsigned so1 = slab(kc + 1);
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
     }
   };
   if constexpr ((FLAGS & F4_DBG_TIME) != 0) tm1 = __builtin_readcyclecounter();
-  for (int kc = 0; kc < nkc; kc += 2) {
+  for (int kc = kc0; kc < kc1; kc += 2) {
     chunk(kc, C0{});
     chunk(kc + 1, C1{});
   }
@@ -245,10 +252,12 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bias[c][g][e] = p.bias[n0 + c * 32 + 8 * g + 4 * half + e];
+      for (int e = 0; e < 4; ++e) bias[c][g][e] = ksp > 1 ? 0.f : p.bias[n0 + c * 32 + 8 * g + 4 * half + e];
   const int wbase = l31 * PP;
   const int rpx = lane / PP, rpi = lane % PP;       // reader: pixel within a pass of 64 / PP pixels, piece
-  const bool leaky = p.leaky != 0;
+  const bool leaky = p.leaky != 0 && ksp == 1;
+  float* const obase = ksp > 1 ? p.part + (size_t)blockIdx.z * ((size_t)p.M * 4) * p.Cout : p.out;   // (p.M = low-resolution pixels)
+  const int ostr = ksp > 1 ? p.Cout : p.ostride;
 #pragma unroll
   for (int ph = 0; ph < 4; ++ph) {
 #pragma unroll
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_fold4_kernel(ConvParams p) {
       const bf4 v = xt[px * PP + (rpi ^ (px & (PP - 1)))];
       const int y = y0 + (px >> 3), x = x0 + 8 * wv + (px & 7);
       if (y < p.H && x < p.W)
-        *reinterpret_cast<bf4*>(p.out + (((size_t)img * 2 * p.H + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1)) * p.ostride + n0 + 4 * rpi) = v;
+        *reinterpret_cast<bf4*>(obase + (((size_t)img * 2 * p.H + 2 * y + (ph >> 1)) * (2 * p.W) + 2 * x + (ph & 1)) * ostr + n0 + 4 * rpi) = v;
     }
   }
   if constexpr ((FLAGS & F4_DBG_TIME) != 0) {
@@ -290,11 +299,12 @@ template <int NCT, int FLAGS>
 hipError_t conv_fold4_launch(const ConvParams& p, hipStream_t s) {
   constexpr int BN = 32 * NCT;
   const size_t lds = (size_t)3 * 12 * 1024;
-  if (p.ksize != 2 || p.fold != 3 || p.nseg != 1 || p.Ctot % 16 || p.Cout % BN || p.ksplit > 1 || p.pool_out || p.pw_out) return hipErrorInvalidValue;
+  if (p.ksize != 2 || p.fold != 3 || p.nseg != 1 || p.Ctot % 16 || p.Cout % BN || p.pool_out || p.pw_out) return hipErrorInvalidValue;
+  if (p.ksplit > 1 && (!p.part || (reinterpret_cast<uintptr_t>(p.part) & 15) || p.ksplit > p.Ctot / 16)) return hipErrorInvalidValue;
   if (p.seg[0].C != p.Ctot || p.seg[0].stride % 4 || p.seg[0].up || (reinterpret_cast<uintptr_t>(p.seg[0].ptr) & 15)) return hipErrorInvalidValue;
   if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
   const int ntx = (p.W + 31) / 32, nty = (p.H + 3) / 4;
-  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, 1);
+  dim3 grid((unsigned)(p.NB * ntx * nty), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   hipLaunchKernelGGL((conv_fold4_kernel<NCT, FLAGS>), grid, dim3(256), lds, s, p);
   return hipGetLastError();
 }

@@ -250,15 +250,16 @@ static hipError_t film_launch_conv_main(const ConvParams& p, int tile, hipStream
 }
 
 hipError_t film_launch_conv(const ConvParams& p, int tile, hipStream_t s) {
-  // split-K is implemented by conv_buf_kernel, conv_wino43_kernel and conv_wino2d_kernel
-  const bool can_split = !(tile & (CONV_TILE_FOLD4 | CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
+  // split-K is implemented by conv_buf_kernel, conv_wino43_kernel, conv_wino2d_kernel and conv_fold4_kernel
+  const bool can_split = !(tile & (CONV_TILE_FOLDX3 | CONV_TILE_SPLIT | CONV_TILE_HALO | CONV_TILE_C3 | CONV_TILE_X3)) &&
                          (!(tile & CONV_TILE_WINO) || (tile & CONV_TILE_F43));
   if (p.ksplit > 1 && !can_split) return hipErrorInvalidValue;
   const hipError_t e = film_launch_conv_main(p, tile, s);
   if (e != hipSuccess || p.ksplit <= 1) return e;
-  if (!p.part || (p.Cout & 3) || (long long)p.M * (p.Cout >> 2) >= (1ll << 32)) return hipErrorInvalidValue;
-  const unsigned units = (unsigned)p.M * (unsigned)(p.Cout >> 2);
-  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((units + 255) / 256), dim3(256), 0, s, p.part, p.bias, p.out, p.M, p.Cout,
+  const long long Mout = (long long)p.M * (p.fold == 3 ? 4 : 1);   // conv_fold4_kernel: M counts the low-resolution pixels, four outputs each
+  if (!p.part || (p.Cout & 3) || Mout * (p.Cout >> 2) >= (1ll << 32)) return hipErrorInvalidValue;
+  const unsigned units = (unsigned)Mout * (unsigned)(p.Cout >> 2);
+  hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((units + 255) / 256), dim3(256), 0, s, p.part, p.bias, p.out, (int)Mout, p.Cout,
                      p.ostride, p.ksplit, p.leaky);
   return hipGetLastError();
 }

@@ -130,6 +130,14 @@ struct Planner {
         f.w_off = L.wf4_off;
         for (int q = 0; q < 4; ++q) f.fold_woff[q] = 0;
         f.tile = (L.cout % 64 == 0 ? F4_4x64 : F4_4x32) | CONV_TILE_FOLD4 | CONV_TILE_XCD;
+        // split-K like the nested kernel's (below): deep K on a small level - the decoder's coarsest layer (K = 1936 on 36x60 low-resolution
+        // pixels of a 1080p tile: 1152 workgroups of 242 chunks on 768 slots = 1.5 rounds; two K ranges = 3 rounds: tools/fold4_bench,
+        // profiles/r06_fold4_bench.log).  Factor from the level size and the layer only - never the batch.
+        if (h->opt_splitk && (int64_t)f.H * f.W <= 4096 && ctot >= 768) {
+          f.ksplit = 2;
+          const int sb = add_scratch("splitk:" + f.tag, (int64_t)f.ksplit * NB * H * W * L.cout);
+          f.part_off = P->bufs[sb].off;
+        }
       }
       f.flops = 2.0 * NB * H * W * L.cout * L.kh * L.kw * L.cin;   // algorithmic FLOPs of the reference op
       f.bytes = 4.0 * NB * H * W * (L.cin / 4.0 + L.cout);

@@ -82,6 +82,33 @@ __global__ void maxdiff_kernel(const float* a, const float* b, size_t n, float* 
   atomicMax(reinterpret_cast<unsigned*>(amax), __float_as_uint(am));
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias, float* __restrict__ out,
+                                                            int M, int Cout, int ostride, int S, int leaky) {   // the engine's conv_splitk_reduce_kernel, restated
+  const int G = Cout >> 2;
+  const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+  if (idx >= (unsigned)M * (unsigned)G) return;
+  const unsigned m = idx / (unsigned)G, g = idx - m * (unsigned)G;
+  const size_t plane = (size_t)M * Cout;
+  const float4* src = reinterpret_cast<const float4*>(part + (size_t)m * Cout + g * 4);
+  float4 a = *reinterpret_cast<const float4*>(bias + g * 4);
+  for (int sidx = 0; sidx < S; ++sidx) {
+    const float4 v = src[(size_t)sidx * (plane >> 2)];
+    a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+  }
+  if (leaky) { a.x = a.x > 0.f ? a.x : 0.2f * a.x; a.y = a.y > 0.f ? a.y : 0.2f * a.y; a.z = a.z > 0.f ? a.z : 0.2f * a.z; a.w = a.w > 0.f ? a.w : 0.2f * a.w; }
+  *reinterpret_cast<float4*>(out + (size_t)m * ostride + g * 4) = a;
+}
+static float* g_part = nullptr;
+template <int NCT, int S>
+static hipError_t fold4_split(const ConvParams& p0, hipStream_t st) {
+  ConvParams p = p0;
+  p.ksplit = S; p.part = g_part;
+  const hipError_t e = conv_fold4_launch<NCT, 4>(p, st);
+  if (e != hipSuccess) return e;
+  const unsigned units = (unsigned)p.M * 4u * (unsigned)(p.Cout >> 2);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((units + 255) / 256), dim3(256), 0, st, p.part, p.bias, p.out, p.M * 4, p.Cout, p.ostride, S, p.leaky);
+  return hipGetLastError();
+}
 typedef hipError_t (*LaunchFn)(const ConvParams&, hipStream_t);
 struct Variant { const char* name; int bn; int fold; LaunchFn fn; };
 static Variant variants[] = {
@@ -92,6 +119,8 @@ static Variant variants[] = {
     {"fold4 x64 plain", 64, 3, conv_fold4_launch<2, 0>},
     {"fold4 x32", 32, 3, conv_fold4_launch<1, 4>},
     {"fold4 x64 time", 64, 3, conv_fold4_launch<2, 4 | F4_DBG_TIME>},
+    {"fold4 x32 split2", 32, 3, fold4_split<1, 2>}, {"fold4 x64 split2", 64, 3, fold4_split<2, 2>},
+    {"fold4 x32 split3", 32, 3, fold4_split<1, 3>}, {"fold4 x64 split4", 64, 3, fold4_split<2, 4>}, {"fold4 x32 split4", 32, 3, fold4_split<1, 4>},
 };
 
 struct Shape { const char* name; int NB, H, W, C, Cout; };   // H, W: the LOW-resolution input grid
@@ -100,6 +129,8 @@ static Shape shapes[] = {
     {"fusion_2_0  4x72x120   512->256", 4, 72, 120, 512, 256},
     {"fusion_1_0  4x144x240  256->128", 4, 144, 240, 256, 128},
     {"fusion_0_0  4x288x480  128->64", 4, 288, 480, 128, 64},
+    {"256:fus_3_0 1x16x16   1936->512", 1, 16, 16, 1936, 512},
+    {"vimeo:fus_3_0 8x16x28 1936->512", 8, 16, 28, 1936, 512},
     {"ragged      3x7x45      48->64", 3, 7, 45, 48, 64},
     {"tiny K      2x4x32      16->64", 2, 4, 32, 16, 64},
     {"K = 32      2x9x33      32->128", 2, 9, 33, 32, 128},
@@ -133,6 +164,7 @@ int main(int argc, char** argv) {
     unsigned long long* d_tm;
     const size_t n_tm = (size_t)sh.NB * ((sh.H + 3) / 4) * ((sh.W + 31) / 32) * (sh.Cout / 32) * 16;
     CK(hipMalloc(&d_tm, n_tm * 8 + 16384));
+    CK(hipMalloc(&g_part, (size_t)4 * Mout * sh.Cout * 4));
     ConvParams p{};
     p.part = reinterpret_cast<float*>(d_tm);
     p.nseg = 1;
@@ -194,6 +226,7 @@ int main(int argc, char** argv) {
              md[0], md[1], ok ? (same_family ? "" : "  ok") : "  MISMATCH");
       fflush(stdout);
     }
+    CK(hipFree(g_part)); g_part = nullptr;
     CK(hipFree(d_tm)); CK(hipFree(d_a)); CK(hipFree(d_w)); CK(hipFree(d_w2)); CK(hipFree(d_w4a)); CK(hipFree(d_w4b)); CK(hipFree(d_b)); CK(hipFree(d_out)); CK(hipFree(d_ref)); CK(hipFree(d_md));
   }
   printf("mismatches: %d\n", bad);
