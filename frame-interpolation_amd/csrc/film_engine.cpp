@@ -608,6 +608,16 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
       h->opt_wino2d = (int)value;
     }
   }
+  else if (!strcmp(key, "w2d_small_px")) {
+    if (value < 0 || value > (1 << 30)) return fail(h, FILM_ERR_INVALID, "w2d_small_px: pixels per image, 0 = never");
+    if ((int)value != h->opt_w2d_small_px) {  // plans carry the kernel choice: drop them
+      if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
+      for (auto& p : h->plans) free_plan(p.get());
+      h->plans.clear();
+      h->last_plan = nullptr;
+      h->opt_w2d_small_px = (int)value;
+    }
+  }
   else if (!strcmp(key, "w2d_min_px")) {
     if (value < 1 || value > (1 << 30)) return fail(h, FILM_ERR_INVALID, "w2d_min_px: pixels per image");
     if ((int)value != h->opt_w2d_min_px) {  // plans carry the kernel choice: drop them

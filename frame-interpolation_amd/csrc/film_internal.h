@@ -213,6 +213,7 @@ struct film_handle {
   int opt_wino2d = 1;     // nested Winograd kernel: 0 never, 1 (default) the deep-K layers of the large levels, 2 every layer that has the copy (tests)
   int opt_w2d_min_px = 1536; // conv_wino2d_kernel runs the 3x3 layers of levels with at least this many pixels per image (planner rule;
                              // profiles/r04_w2d_min_px_ab.log: 8 or more 8x32 patches per image - 32x56 yes, 32x32 no)
+  int opt_w2d_small_px = 256; // ... and of smaller levels down to this many pixels when the level fills >= 65 % of its 8x32 tiles (0: never)
   int opt_w2d_splitk = 1; // 1: split-K for the nested kernel's K >= 768 layers on levels of <= 4096 pixels, S = min(4, K / 384) (planner rule; option "w2d_splitk" for A/B runs)
   int opt_w2d_shape = -1; // tests: >= 0 = every conv_wino2d_kernel op that can run this Wino2dTile shape does
   int opt_fold4_shape = -1; // tests: >= 0 = every conv_fold4_kernel op that can run this Fold4Tile shape does

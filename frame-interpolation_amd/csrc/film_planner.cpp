@@ -130,11 +130,12 @@ struct Planner {
         f.w_off = L.wf4_off;
         for (int q = 0; q < 4; ++q) f.fold_woff[q] = 0;
         f.tile = (L.cout % 64 == 0 ? F4_4x64 : F4_4x32) | CONV_TILE_FOLD4 | CONV_TILE_XCD;
-        // split-K like the nested kernel's (below): deep K on a small level - the decoder's coarsest layer (K = 1936 on 36x60 low-resolution
-        // pixels of a 1080p tile: 1152 workgroups of 242 chunks on 768 slots = 1.5 rounds; two K ranges = 3 rounds: tools/fold4_bench,
-        // profiles/r06_fold4_bench.log).  Factor from the level size and the layer only - never the batch.
-        if (h->opt_splitk && (int64_t)f.H * f.W <= 4096 && ctot >= 768) {
-          f.ksplit = 2;
+        // split-K like the nested kernel's (below), for deep K on a TINY level: the decoder's coarsest layer of a 256x256 pair (K = 1936 on
+        // 16x16 low-resolution pixels = 4 pixel tiles x 16 channel blocks: 64 workgroups of 242 chunks) 0.139 -> 0.048 ms with four K
+        // ranges; on the 36x60 level of a 1080p tile (1152 workgroups) every split LOSES (0.589 -> 0.61-0.64 ms), eight 448x256 pairs
+        // (16x28) lose 10 % (tools/fold4_bench, profiles/r06_fold4_bench.log).  Factor from the level size and the layer only - never the batch.
+        if (h->opt_splitk && (int64_t)f.H * f.W <= 1024 && ctot >= 768) {
+          f.ksplit = 4;
           const int sb = add_scratch("splitk:" + f.tag, (int64_t)f.ksplit * NB * H * W * L.cout);
           f.part_off = P->bufs[sb].off;
         }
@@ -205,8 +206,14 @@ struct Planner {
     // published net; a property of the layer's buffers, so still a function of the layer only)
     bool w2d_layout = ctot % 16 == 0 && out.off % 4 == 0 && out.stride % 4 == 0;
     for (int i = 0; i < op.nseg; ++i) w2d_layout = w2d_layout && segs[i].v.C % 16 == 0 && segs[i].v.off % 4 == 0 && segs[i].v.stride % 4 == 0;
+    // Round 6: ... and on SMALLER levels (>= opt_w2d_small_px = 256 pixels) whose shape fills at least 65 % of its 8-row x 32-pixel tiles:
+    // 18x30 (a 1080p tile's level 5: 70 %), 32x32 (a 256x256 pair: 100 %), 16x28 (a 448x256 pair: 87 %) yes, 16x16 (50 %) and 9x15 (26 %)
+    // no - its split-K (round 5) fills the chip where the tile count does not.  A/B of the threshold over three configs:
+    // profiles/r06_w2d_small_levels_ab.log (256x256 2.43 -> 2.35 ms, eight 448x256 pairs 15.7 -> 15.1, 1080p -0.1 ms).
+    const int64_t w2d_tile_px = (int64_t)((H + 7) / 8) * 8 * ((W + 31) / 32) * 32;
+    const bool w2d_level = px >= h->opt_w2d_min_px || (h->opt_w2d_small_px > 0 && px >= h->opt_w2d_small_px && px * 100 >= 65 * w2d_tile_px);
     if (L.w2d_off >= 0 && w2d_layout && !any_up && h->opt_precision == 0 && op.split == 0 &&
-        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && px >= h->opt_w2d_min_px)))
+        (h->opt_wino2d == 2 || (h->opt_wino2d == 1 && h->opt_wino == 1 && w2d_level)))
       op.wino = 4;
     if (op.split || op.wino) op.halo = 0;
 #ifndef FILM_EXTRA_FAMILIES

@@ -191,10 +191,12 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "halo_all" 0/1 [extra] run every eligible 3x3 convolution on the halo-staged kernels whatever its size (default 0:
  *                  only where measured faster); "tune_ms" n: autotune spends at least n ms per candidate.
  *                  Test / tuning knobs; "halo_all" drops the cached plans.
- *   "wino2d"  0/1/2  1 (default): the deep-K 3x3 convolutions (>= 208 input channels, or 128 -> 32) of levels with >= 8192 pixels run the nested
+ *   "wino2d"  0/1/2  1 (default): every 3x3 convolution whose channels come in sixteens, on levels of >= "w2d_min_px" (1536) pixels per image
+ *                  - and on smaller ones down to "w2d_small_px" (256) pixels that fill >= 65 % of their 8-row x 32-pixel tiles - runs the nested
  *                  Winograd form F(4,3) along x times F(2,3) along y (conv_wino2d_kernel: 3 multiplies per output where the 1-D
  *                  F(4,3) kernel spends 4.5 and the direct convolution 9; fp32 throughout, rounding at the level of the 1-D form).
  *                  0: never.  2: every layer that has the weight copy, on every level (tests).  Drops the cached plans.
+ *   "w2d_min_px" n / "w2d_small_px" n  the two level-size thresholds of that rule (A/B runs; a function of the level only - never the batch).
  *   "w2d_splitk" 0/1  1 (default): the nested kernel's K >= 768 layers on levels of <= 4096 pixels per image (the 36x60 level of a 1080p
  *                  tile, the 64x64 level of a 256x256 pair) run as up to four K ranges + the ordered reduction, like "splitk"
  *                  (which also switches it off); factor from the level size and the layer only.  Drops the cached plans.

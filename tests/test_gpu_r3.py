@@ -391,12 +391,14 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
 
 
 def test_default_plan_uses_the_nested_kernel_on_the_deep_layers_of_a_1080p_tile(published):
-    """The default plan of a 960x576 tile: conv_wino2d_kernel on every 3x3 layer (K = 32 ... 2448) of the levels with >= 1536 pixels, and
-    the image stays within the usual distance of the plan without it (the tile is oracle-checked in test_gpu_configs)."""
+    """The default plan of a 960x576 tile: conv_wino2d_kernel on every 3x3 layer (K = 32 ... 2448) of the levels with >= 1536 pixels - and,
+    since round 6, of the 18x30 level, which fills 70 % of its 8 x 32 tiles - and the image stays within the usual distance of the plan
+    without it (the tile is oracle-checked in test_gpu_configs)."""
     opt, w, eng = published
     plan = eng.plan(1, 576, 960)
     w2d = [(o['tag'], o['H'], o['W'], o['Ctot']) for o in plan['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4]
-    assert len(w2d) >= 30 and all(k >= 32 and hh * ww >= 1536 for _, hh, ww, k in w2d), w2d
+    assert len(w2d) >= 30 and all(k >= 32 and (hh * ww >= 1536 or (hh, ww) == (18, 30)) for _, hh, ww, k in w2d), w2d
+    assert any((hh, ww) == (18, 30) for _, hh, ww, _ in w2d) and not any((hh, ww) == (9, 15) for _, hh, ww, _ in w2d)
     x0, x1 = TI.frame_pair(1, 576, 960, seed=2)
     a = eng.forward(x0, x1)
     eng.set_option('wino2d', 0)

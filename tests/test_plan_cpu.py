@@ -15,6 +15,12 @@ import pytest
 from conftest import oracle_options, prefers_extra_families, ROOT
 
 
+def _w2d_level(h, w):
+    """The level-size rule of conv_wino2d_kernel (film_planner.cpp): >= 1536 pixels, or >= 256 pixels filling >= 65 % of the 8 x 32 tiles."""
+    px = h * w
+    return px >= 1536 or (px >= 256 and px * 100 >= 65 * (-(-h // 8) * 8) * (-(-w // 32) * 32))
+
+
 def test_library_exports_every_declared_symbol():
     from film_hip import engine
     lib = engine.load_library()
@@ -218,7 +224,9 @@ def test_plan_interpreter_matches_oracle_published_64(published_packed):
     # [mu][nu] copy of those layers above) AND "lanes" = 3 (the op order of option "lanes" = 2 - coarse decoder levels emitted
     # right behind the aligned levels they read, on the side lane - at this small size) in ONE more interpreter run: same ops,
     # another order, another kernel family; the interpreter's arithmetic does not depend on the family -> same bits
-    assert all(o['H'] * o['W'] >= 1536 for o in plan['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4)      # default rule: large levels only
+    # default rule: levels of >= 1536 pixels, and smaller ones (>= 256) that fill >= 65 % of their 8 x 32 tiles (here: 32x32 yes, 16x16 no)
+    assert all(_w2d_level(o['H'], o['W']) for o in plan['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4)
+    assert {(o['H'], o['W']) for o in plan['ops'] if o['kind'] == 'conv_mfma' and o['wino'] == 4} == {(64, 64), (32, 32)}
     eng.set_option('wino2d', 2)
     eng.set_option('lanes', 3)
     plan3 = eng.plan(1, 64, 64)
@@ -264,7 +272,7 @@ def test_precision_modes_choose_kernel_families_by_shape_only():
                 t = op['tile']
                 assert bool(t & FOLDX3) == (op['fold'] == 2 and op['split'] == 2)
                 assert bool(t & WINO) == (op['wino'] in (1, 2, 3)) and bool(t & SPLIT) == (op['split'] != 0 and not op['fold'])
-                assert bool(t & W2D) == (op['wino'] == 4) and (op['wino'] != 4 or (op['Ctot'] % 16 == 0 and op['H'] * op['W'] >= 1536))
+                assert bool(t & W2D) == (op['wino'] == 4) and (op['wino'] != 4 or (op['Ctot'] % 16 == 0 and _w2d_level(op['H'], op['W'])))
                 assert bool(t & X3) == (op['wino'] == 2 or (op['split'] == 2 and not op['fold']))
                 assert bool(t & F43) == (op['wino'] == 3)
         assert per_batch[0] == per_batch[1]
@@ -526,8 +534,8 @@ def test_second_weight_set_repacks_every_layout_group_a_cached_plan_reads(tiny_w
 
 def test_nested_winograd_rule_is_a_function_of_layer_and_level_size():
     """conv_wino2d_kernel runs every 3x3 layer whose channels come in sixteens / thirty-twos (round 4: K = 32 ... 2448, pooled stages
-    and the RGB-head layer included - its epilogue fuses both) on levels with >= 1536 pixels - whatever the batch size, small frames
-    too.  Levels below 1536 pixels and the 3-channel first layers never get it; "w2d_shape" forces one tile shape where it fits and
+    and the RGB-head layer included - its epilogue fuses both) on levels with >= 1536 pixels and on smaller ones (>= 256) that fill 65 % of
+    their 8 x 32 tiles (32x32, 16x28, 18x30: round 6) - whatever the batch size, small frames too.  Other levels and the 3-channel first layers never get it; "w2d_shape" forces one tile shape where it fits and
     is validated."""
     from film_hip.engine import FilmEngine, FilmError
     from film_hip.options import PUBLISHED
@@ -540,15 +548,15 @@ def test_nested_winograd_rule_is_a_function_of_layer_and_level_size():
         one = nested(1, h, w)
         assert one == nested(3, h, w)                                  # never a function of the batch
         for tag, hh, ww in one:
-            assert hh * ww >= 1536, (tag, hh, ww)
+            assert _w2d_level(hh, ww), (tag, hh, ww)
         # ... and the other way round: every 3x3 layer of such a level that is not a first layer runs it
         for o in eng.plan(1, h, w)['ops']:
-            if o['kind'] == 'conv_mfma' and o['ksize'] == 3 and not o.get('c3') and o['H'] * o['W'] >= 1536:
+            if o['kind'] == 'conv_mfma' and o['ksize'] == 3 and not o.get('c3') and _w2d_level(o['H'], o['W']):
                 assert o['wino'] == 4, o['tag']
     small = [t for t, _, _ in nested(1, 256, 256)]
     assert any('flow_predictor_1/conv_0' in t for t in small) and any('flow_predictor_0/conv_0' in t for t in small), small
     big = [t for t, _, _ in nested(4, 576, 960)]
-    assert len(big) == 46 and sum('+pool' in t for t in big) == 12 and any(t.endswith('convs_0_2+output_conv') for t in big), big
+    assert len(big) == 56 and sum('+pool' in t for t in big) == 15 and any(t.endswith('convs_0_2+output_conv') for t in big), big
     for o in eng.plan(1, 256, 448)['ops']:
         if o['kind'] == 'conv_mfma' and o['wino'] == 4:
             assert o['Ctot'] % 16 == 0 and o['Cout'] % 32 == 0 and o['w2d_off'] >= 0, o['tag']
