@@ -1,7 +1,7 @@
 // conv_wino43_impl.h -- 3x3 Conv2D('same') + bias + leaky_relu with the 1-D Winograd transform F(4,3) along x, fp32
 // MFMA: per FOUR output pixels of a row 6 x 3 (nu, dy) matrix steps per K chunk instead of 36 (direct) or 24 (F(2,3),
 // conv_wino_impl.h) - 2x / 1.33x fewer v_mfma_f32_32x32x2_f32.  The fp32 matrix pipe is power limited on this part
-// (every large layer of the fp32 path lands at 105-128 TFLOP/s executed whatever the kernel), so fewer
+// (every large layer of the fp32 path lands at 105-128 TFLOP/s executed whatever the kernel, profiles/HISTORY.md 4.1), so fewer
 // multiplies per output is what is left to buy time with.
 //
 // For an output row y and the pixel quad x = 4t .. 4t+3 with inputs d0..d5 = in[.][4t-1 .. 4t+4] (Lavin & Gray's
@@ -40,7 +40,7 @@ enum { W43_F_PF2 = 32768,      // activation loads requested TWO chunks ahead (s
                                // per CU), no weight stores, two barriers per chunk instead of three
 // (Rounds 2-3 carried experiment flags here - wave priorities around the MFMA groups (-1..-3 %), persistent workgroups that request
 // the next pair's loads in front of the epilogue (no gain), timing ablations - driven by tools/retired/conv_bench.hip; their
-// measurements are in DESIGN.md 9 and profiles/r0[23]_*; the code went with round 4.)
+// measurements are in profiles/HISTORY.md 9 and profiles/r0[23]_*; the code went with round 4.)
 
 template <int TH, int BN, int TM, int TN, int FLAGS, int QW = 32, int NH = 2>
 __global__ __launch_bounds__(((TH * QW / 32) / TM) * (BN / (32 * TN)) * 64 * NH, ((FLAGS & W43_F_BG) != 0 && BN == 32 && QW <= 16) ? 4 : 2) void conv_wino43_kernel(ConvParams p) {   // 2 waves per SIMD: <= 256 VGPRs, two 4-wave workgroups per CU (W43_F_BG 32-channel tile: 4 -> <= 128 VGPRs, four per CU)
