@@ -450,9 +450,9 @@ int film_to_uint8(const float* src, unsigned char* dst, int64_t n, void* stream)
 #else
 #define FILM_FLAVOUR ""
 #endif
-// "gfx950;film_hip r5;src=<sha1[:12] of csrc/ + include/film_hip.h>[+extra]": ties tune caches, bench lines and PMC summaries to the
+// "gfx950;film_hip r6;src=<sha1[:12] of csrc/ + include/film_hip.h>[+extra]": ties tune caches, bench lines and PMC summaries to the
 // kernel sources they were produced with (film_hip/build.py source_id(), `make print-src-id`)
-const char* film_version(void) { return "gfx950;film_hip r5;src=" FILM_SRC_ID FILM_FLAVOUR; }
+const char* film_version(void) { return "gfx950;film_hip r6;src=" FILM_SRC_ID FILM_FLAVOUR; }
 
 int film_default_config(film_config* cfg) {
   if (!cfg) return FILM_ERR_INVALID;
