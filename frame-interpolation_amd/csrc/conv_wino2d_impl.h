@@ -640,6 +640,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   }
 }
 
+inline int& conv_wino2d_debug_extra_lds() { static int v = 0; return v; }   // tools only: bytes of dynamic LDS added to a launch (occupancy experiments)
+
 template <int BN, int FLAGS, int NS = 3>
 hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   constexpr bool CHAIN = (FLAGS & W2D_F_CHAIN) != 0;
@@ -663,6 +665,6 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
   const int ntiles = p.NB * ntx * nty, chain = CHAIN ? p.chain : 1;
   dim3 grid((unsigned)((ntiles + chain - 1) / chain), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds, s, p);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds + (size_t)conv_wino2d_debug_extra_lds(), s, p);
   return hipGetLastError();
 }

@@ -629,12 +629,13 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
     }
   }
   else if (!strcmp(key, "w2d_splitk")) {
-    if ((value != 0) != (h->opt_w2d_splitk != 0)) {  // plans carry the split factors: drop them
+    if (value < 0 || value > 16) return fail(h, FILM_ERR_INVALID, "w2d_splitk: 0 (off), 1 (default rule) or 2..16 (A/B: the cap on levels of <= 1024 pixels)");
+    if ((int)value != h->opt_w2d_splitk) {  // plans carry the split factors: drop them
       if (!h->plan_only) { (void)hipSetDevice(h->device); (void)hipDeviceSynchronize(); }
       for (auto& p : h->plans) free_plan(p.get());
       h->plans.clear();
       h->last_plan = nullptr;
-      h->opt_w2d_splitk = value != 0;
+      h->opt_w2d_splitk = (int)value;
     }
   }
   else if (!strcmp(key, "w2d_shape")) {

@@ -5,6 +5,8 @@
 // crc32c helper of the SavedModel reader.  Replaces the variable-restore half of tf.saved_model.load (eval/interpolator.py:148).
 #include "film_internal.h"
 
+#include <dlfcn.h>
+
 namespace film_internal {
 
 // ---------------------------------------------------------------------------------------------
@@ -563,6 +565,44 @@ int film_import_packed(film_t* h, const float* src, int64_t n, int mem_kind) {
     h->host_w[L.name + "/bias"] = std::move(bq);
   }
   return film_finalize(h);
+}
+
+// ---- RCCL weight broadcast (include/film_hip.h).  ncclBroadcast is looked up at run time: a process has ONE RCCL (PyTorch bundles its own),
+// and a host that brings a communicator has it loaded already.
+namespace {
+typedef int (*nccl_bcast_fn)(const void*, void*, size_t, int /* ncclDataType_t */, int, void* /* ncclComm_t */, hipStream_t);
+nccl_bcast_fn resolve_nccl_broadcast(std::string* where) {
+  if (void* f = dlsym(RTLD_DEFAULT, "ncclBroadcast")) { *where = "the process"; return reinterpret_cast<nccl_bcast_fn>(f); }
+  for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    if (void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))
+      if (void* f = dlsym(lib, "ncclBroadcast")) { *where = name; return reinterpret_cast<nccl_bcast_fn>(f); }
+  }
+  return nullptr;
+}
+}  // namespace
+
+int film_bcast_weights(film_t* h, void* nccl_comm, int root, int rank, void* stream) {
+  if (!h || !nccl_comm || root < 0 || rank < 0) return fail(h, FILM_ERR_INVALID, "bad argument");
+  if (h->plan_only) return fail(h, FILM_ERR_NO_DEVICE, "plan-only handle: the RCCL broadcast needs a HIP device");
+  if (rank == root && !h->finalized) return fail(h, FILM_ERR_STATE, "the root rank must hold a finalized weight set (film_finalize / film_load_bundle)");
+  static std::string where;
+  static const nccl_bcast_fn bcast = resolve_nccl_broadcast(&where);
+  if (!bcast) return fail(h, FILM_ERR_NOTFOUND, "ncclBroadcast not found: no RCCL in the process and librccl.so cannot be loaded");
+  const int64_t n = flat_floats(h);
+  HIPCHK(h, hipSetDevice(h->device));
+  float* blob = nullptr;
+  HIPCHK(h, hipMalloc(&blob, (size_t)n * sizeof(float)));
+  hipStream_t s = stream ? (hipStream_t)stream : h->stream;
+  int rc = FILM_OK;
+  if (rank == root) rc = film_export_packed(h, blob, n, FILM_MEM_DEVICE);
+  if (rc == FILM_OK) {
+    const int nrc = bcast(blob, blob, (size_t)n, 7 /* ncclFloat32 */, root, nccl_comm, s);
+    if (nrc != 0) rc = fail(h, FILM_ERR_HIP, "ncclBroadcast (from %s) failed with ncclResult_t %d", where.c_str(), nrc);
+  }
+  if (rc == FILM_OK && hipStreamSynchronize(s) != hipSuccess) rc = fail(h, FILM_ERR_HIP, "hipStreamSynchronize behind the broadcast failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc == FILM_OK && rank != root) rc = film_import_packed(h, blob, n, FILM_MEM_DEVICE);
+  (void)hipFree(blob);
+  return rc;
 }
 
 // the kernel-layout blob (debug / tests): the packed prefix [0, *n)

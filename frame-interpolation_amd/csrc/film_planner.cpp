@@ -274,6 +274,7 @@ struct Planner {
     if (h->opt_splitk && h->opt_w2d_splitk && op.wino == 4 && L.cout % 4 == 0) {
       int S = 1;
       if (px <= 4096 && ctot >= 768) S = std::min(4, ctot / 384);
+      if (h->opt_w2d_splitk > 1 && px <= 1024 && ctot >= 384) S = std::min(h->opt_w2d_splitk, ctot / 192);   // A/B knob: a higher cap on tiny levels
       if (S > 1) {
         op.ksplit = S;
         const int sb = add_scratch("splitk:" + op.tag, (int64_t)S * M * L.cout);

@@ -48,7 +48,7 @@ EXPORTED_SYMBOLS = (
     'film_finalize', 'film_packed_size', 'film_export_packed', 'film_import_packed', 'film_export_layouts', 'film_forward',
     'film_interpolate',
     'film_set_option', 'film_profile_json', 'film_plan_json', 'film_get_tap', 'film_crc32c', 'film_version',
-    'film_export_tune', 'film_import_tune', 'film_to_uint8', 'film_load_bundle')
+    'film_export_tune', 'film_import_tune', 'film_to_uint8', 'film_load_bundle', 'film_bcast_weights')
 
 _lib = None
 
@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None) -> ctypes.CDLL:
     lib.film_import_tune.argtypes = [vp, cp]
     lib.film_to_uint8.argtypes = [vp, vp, ctypes.c_int64, vp]
     lib.film_load_bundle.argtypes = [vp, cp, ctypes.c_int, ctypes.c_char_p, ctypes.c_int64, i64p]
+    lib.film_bcast_weights.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp]
     for name in EXPORTED_SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is ctypes.c_int and name not in ('film_destroy',):
@@ -283,6 +284,13 @@ class FilmEngine:
 
     def export_packed_device(self, ptr: int, n_floats: int) -> None:
         self._check(self._lib.film_export_packed(self._h, ctypes.c_void_p(ptr), n_floats, FILM_MEM_DEVICE))
+
+    def bcast_weights(self, nccl_comm: int, root: int, rank: int, stream: int = 0) -> None:
+        """film_bcast_weights: the RCCL broadcast of the parameter blob behind the C-ABI, over the CALLER's ncclComm_t (an integer
+        handle here) - for hosts without torch.distributed; film_hip/sharding.py::broadcast_weights is the torch.distributed route."""
+        self._check(self._lib.film_bcast_weights(self._h, ctypes.c_void_p(nccl_comm), root, rank, ctypes.c_void_p(stream)))
+        if rank != root:
+            self._load_tune_cache()
 
     # -- compute ----------------------------------------------------------------------------
     def forward(self, x0: np.ndarray, x1: np.ndarray) -> np.ndarray:

@@ -95,6 +95,15 @@ int film_packed_size(film_t* h, int64_t* n_floats);
 int film_export_packed(film_t* h, float* dst, int64_t capacity_floats, int mem_kind);
 int film_import_packed(film_t* h, const float* src, int64_t n_floats, int mem_kind);
 
+/* The weight broadcast itself, for hosts without torch.distributed (north_star: "RCCL broadcast of weights over xGMI"; the
+ * reference has nothing to replace here - every beam worker calls tf.saved_model.load on its own, eval/interpolator_cli.py:127-150).
+ * Collective over `nccl_comm` (an ncclComm_t of the CALLER - the library creates no communicator and links no RCCL: ncclBroadcast is
+ * resolved at run time from the RCCL already in the process, else from librccl.so): rank `root` must hold a finalized weight set and sends
+ * the flat parameter blob (film_packed_size floats, staged in a device buffer of handle `h`'s GPU), every other rank receives it and
+ * film_import_packed()s it (= film_finalize with the received set).  `rank` = the caller's rank in the communicator; `stream` = the HIP
+ * stream the broadcast is enqueued on (NULL: the handle's own), synchronised before the function returns.  Every rank must call it. */
+int film_bcast_weights(film_t* h, void* nccl_comm, int root, int rank, void* stream);
+
 /* Debug / tests: the kernel-layout blob packed so far (offsets as in film_plan_json; "pack_groups" option packs more).
  * dst == NULL: size query. */
 int film_export_layouts(film_t* h, float* dst, int64_t capacity_floats, int64_t* n_floats);

@@ -60,3 +60,65 @@ def test_two_ranks_strong_scaling_tile_sharded_recursion_matches_one_rank():
     assert two['ranks']['communicator_size'] == 2 and two['ranks']['backend'] == 'nccl'
     assert two['ranks']['gather_ms_per_step'] is not None
     assert two['output_crc32'] == one['output_crc32'] and one['output_crc32'] is not None
+
+
+def _bcast_rank(rank, world, uid_path, q):
+    import ctypes
+    import time
+    import zlib
+    import numpy as np
+    import torch
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    torch.cuda.set_device(rank)
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), 'lib', 'librccl.so'))
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [('internal', ctypes.c_char * 128)]
+    uid = UniqueId()
+    if rank == 0:
+        assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+        with open(uid_path + '.tmp', 'wb') as f:
+            f.write(bytes(uid))
+        os.replace(uid_path + '.tmp', uid_path)
+    else:
+        for _ in range(600):
+            if os.path.exists(uid_path):
+                break
+            time.sleep(0.1)
+        ctypes.memmove(ctypes.byref(uid), open(uid_path, 'rb').read(), 128)
+    comm = ctypes.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), world, uid, rank) == 0
+    eng = FilmEngine(TINY, device=rank)
+    if rank == 0:
+        eng.set_weights(W.make_synthetic_weights(TINY, seed=0))
+    eng.bcast_weights(comm.value, root=0, rank=rank)
+    q.put((rank, zlib.crc32(np.ascontiguousarray(eng.export_packed()).tobytes())))
+    eng.close()
+
+
+def test_weight_broadcast_behind_the_c_abi_two_ranks(tmp_path):
+    """film_bcast_weights with NO torch.distributed: two processes, one GPU each, an RCCL communicator made by hand (ncclGetUniqueId on
+    rank 0, handed over through a file); rank 1 ends up with rank 0's parameter blob."""
+    import multiprocessing as mp
+    import zlib
+    import numpy as np
+    from film_hip import weights as W
+    from film_hip.engine import FilmEngine
+    from film_hip.options import TINY
+    ref = FilmEngine(TINY, device=-1)
+    ref.set_weights(W.make_synthetic_weights(TINY, seed=0))
+    want = zlib.crc32(np.ascontiguousarray(ref.export_packed()).tobytes())
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_rank, args=(r, 2, str(tmp_path / 'uid'), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert got == {0: want, 1: want}
+

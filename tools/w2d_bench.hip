@@ -140,6 +140,14 @@ static hipError_t w2d_chain(const ConvParams& p0, hipStream_t st) {
   return conv_wino2d_launch<BN, 4 | W2D_F_CHAIN | FL, NS>(p, st);
 }
 #define W2C(NAME, BN, NS, CH) {"w2d " NAME, BN, 1, w2d_chain<BN, NS, CH, 0>}
+// occupancy experiment: the unchained two-stage tile with EXTRA KB of dynamic LDS it does not use
+template <int EXTRA_KB>
+static hipError_t w2d_ns2_lds(const ConvParams& p, hipStream_t st) {
+  conv_wino2d_debug_extra_lds() = EXTRA_KB * 1024;
+  const hipError_t e = conv_wino2d_launch<32, 4, 2>(p, st);
+  conv_wino2d_debug_extra_lds() = 0;
+  return e;
+}
 #define W43(NAME, BN, ...) {"w43 " NAME, BN, 2, conv_wino43_launch<__VA_ARGS__>}
 static Variant variants[] = {
     W43("q16 4x64 t21 p2", 64, 4, 64, 2, 1, 4 | W43_F_PF2, 16), W43("q16 4x64 n1 p2", 64, 4, 64, 1, 1, 4 | W43_F_PF2, 16, 1), W43("q8 8x64 t21 p2", 64, 8, 64, 2, 1, 4 | W43_F_PF2, 8),
@@ -150,6 +158,7 @@ static Variant variants[] = {
     W2C("32 ns2 ch1", 32, 2, 1), W2C("32 ns2 ch2", 32, 2, 2), W2C("32 ns2 ch4", 32, 2, 4), W2C("32 ns2 ch8", 32, 2, 8),
     W2C("64 ns3 ch1", 64, 3, 1), W2C("64 ns3 ch2", 64, 3, 2), W2C("64 ns3 ch4", 64, 3, 4), W2C("64 ns3 ch8", 64, 3, 8),
     {"w2d 32 ns2 plain", 32, 1, conv_wino2d_launch<32, 4, 2>},
+    {"w2d 32 ns2 lds+24", 32, 1, w2d_ns2_lds<24>}, {"w2d 32 ns2 lds+30", 32, 1, w2d_ns2_lds<30>}, {"w2d 32 ns2 lds+32", 32, 1, w2d_ns2_lds<32>},
     W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
     {"w2d 32 ns2 ch4 time", 32, -1, w2d_chain<32, 2, 4, W2D_DBG_TIME>}, {"w2d 64 ns3 ch4 time", 64, -1, w2d_chain<64, 3, 4, W2D_DBG_TIME>},
     W2N("64 abl-noxf", 64, 4 | W2D_DBG_NOXF), W2N("32 abl-noxf", 32, 4 | W2D_DBG_NOXF),
