@@ -66,6 +66,15 @@ __device__ __forceinline__ void w2d_for_each(F&& f, std::integer_sequence<int, G
 
 // BN = 32 NG output channels per workgroup, one wave per (mu, 32 channels): 4 NG waves, two waves per SIMD either way (BN = 64: one
 // workgroup of 8 waves per CU; BN = 32: two of 4 - their prologues / epilogues overlap the other's K loop: the usual winner)
+// the multiply-shift quotients of the DMA slot decomposition (slot / 148, rest / 36, rest / 9) are exact on the ranges they are used on
+constexpr bool w2d_slot_quotients_exact() {
+  for (unsigned s = 0; s < 1536u; ++s) if (((s * 443u) >> 16) != s / 148u) return false;
+  for (unsigned s = 0; s < 148u; ++s) if (((s * 1821u) >> 16) != s / 36u) return false;
+  for (unsigned s = 0; s < 36u; ++s) if (((s * 7282u) >> 16) != s / 9u) return false;
+  return true;
+}
+static_assert(w2d_slot_quotients_exact(), "slot quotients");
+
 template <int BN, int FLAGS, int NS_ = 3>
 __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_wino2d_kernel(ConvParams p) {
   constexpr int QW = 8, TH = 8, HR = TH + 2, PXW = 4 * QW, PW = PXW + 2;
@@ -78,6 +87,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   static_assert(NS == 2 || NS == 3, "stages");
   constexpr int IPW = NREQ / NW;                // requests per wave and super-chunk
   static_assert(NREQ % NW == 0, "requests per wave");
+  static_assert(RP4 == 148 && MO4 == 36 && CO4 == 9 && NREQ * 64 <= 1536, "the slot quotients below are made for this layout");
   static_assert(HR * RP4 <= STAGE4, "stage size");
   constexpr bool XF = (FLAGS & W2D_F_XFIRST) != 0;
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -94,6 +104,11 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   unsigned long long rt0 = 0;
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { rt0 = __builtin_amdgcn_s_memrealtime(); tm0 = __builtin_readcyclecounter(); }
 
+  // Prologue diet (round 6).  With two workgroups per CU the ~500 instructions between kernel entry and the first DMA request issue at
+  // ~19 cycles each - the co-resident workgroup's K loop owns the issue slots - i.e. 9 000-11 000 cycles of a 45 000-cycle workgroup
+  // (profiles/r06_w2d_valu_diet.log).  So: quotients by host-made reciprocals (ConvParams::mg_*; exact for x d < 2^32, which the
+  // launcher checks), unsigned slot arithmetic without branches, and no accumulator clearing (the first chunk's MFMAs take C = 0).
+  auto udiv = [](unsigned x, unsigned d, unsigned magic) -> unsigned { return magic ? __umulhi(x, magic) : x / d; };
   int bx = blockIdx.x, by = blockIdx.y;
   if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
     const int nbx = gridDim.x, nby = gridDim.y;
@@ -103,7 +118,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const int q = nwg >> 3, r = nwg & 7;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int nl = base + idx;
-    bx = nl / nby;
+    bx = (int)udiv((unsigned)nl, (unsigned)nby, p.mg_nby);
     by = nl - bx * nby;
   }
   // Chained tiles (W2D_F_CHAIN): this workgroup owns the pixel tiles [g0, g0 + nt) of the launch, nt <= p.chain, one after the other.
@@ -117,8 +132,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int chain = CHAIN ? (p.chain > 1 ? p.chain : 1) : 1;
   const int g0 = bx * chain;
   const int nt = CHAIN ? min(chain, p.NB * tpi - g0) : 1;       // tiles of this workgroup
-  int img = g0 / tpi;
-  int y0 = ((g0 - img * tpi) / ntx) * TH, x0 = ((g0 - img * tpi) % ntx) * PXW;   // the tile the MFMAs / the epilogue are at
+  int img = (int)udiv((unsigned)g0, (unsigned)tpi, p.mg_tpi);
+  const int trow0 = (int)udiv((unsigned)(g0 - img * tpi), (unsigned)ntx, p.mg_ntx);
+  int y0 = trow0 * TH, x0 = (g0 - img * tpi - trow0 * ntx) * PXW;   // the tile the MFMAs / the epilogue are at
   int c_t = 0, c_img = img, c_y0 = y0, c_x0 = x0;               // the tile the DMA cursor is at
   const int n0 = by * BN;
 
@@ -140,21 +156,27 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // segment set-up forms the offsets from it and the cursor's tile - behind an opaque copy, or hipcc hoists the unpacked fields out
   // of the tile loop (18 registers, spilled, reloaded with s_waitcnt vmcnt(0) in the middle of the K loop).
   unsigned rpk[IPW];
+  auto quot16 = [](unsigned x, unsigned magic) -> unsigned { unsigned q; asm("v_mul_u32_u24 %0, %1, %2\n\tv_lshrrev_b32 %0, 16, %0" : "=v"(q) : "v"(x), "s"(magic)); return q; };
+  auto mad24 = [](unsigned a, int b, unsigned c) -> unsigned { unsigned q; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(q) : "v"(a), "s"(b), "v"(c)); return q; };
   auto set_rpk = [&]() {   // for the cursor's tile (chained: tile independent, called once)
     const int H = p.H, W = p.W;
 #pragma unroll
     for (int n = 0; n < IPW; ++n) {
-      const int sl = 64 * (wv + NW * n) + lane;
-      const int r = sl / RP4, rem = sl - r * RP4;
-      const int m = rem / MO4, rr = rem - m * MO4;
-      const int c = rr / CO4, k = rr - c * CO4;
-      const int px = 4 * k + m;
+      // slot -> (halo row r, pixel 4 k + m, piece c): multiply-shift quotients, exact on [0, NREQ * 64) (static_asserts below)
+      // (24-bit forms spelled out: hipcc does not know that a slot number is small and emits the quarter-rate v_mul_lo_u32 / v_mad_u64_u32 -
+      // every vector instruction of a prologue is taken from the co-resident workgroup's matrix pipe)
+      const unsigned sl = 64u * (unsigned)(wv + NW * n) + (unsigned)lane;
+      const unsigned r = quot16(sl, 443u), rem = mad24(r, -RP4, sl);
+      const unsigned m = quot16(rem, 1821u), rr = mad24(m, -MO4, rem);
+      const unsigned c = quot16(rr, 7282u), k = mad24(c, -CO4, rr);
+      const unsigned px = 4u * k + m;
+      const unsigned slot_ok = (unsigned)(r < (unsigned)HR) & (unsigned)(rem < 4u * MO4) & (unsigned)(px < (unsigned)PW);
       if constexpr (CHAIN) {
-        rpk[n] = (unsigned)r | (unsigned)px << 8 | (unsigned)c << 16 | ((r < HR && rem < 4 * MO4 && px < PW) ? 0x80000000u : 0u);
+        rpk[n] = r | px << 8 | c << 16 | (slot_ok ? 0x80000000u : 0u);
       } else {
-        const int y = c_y0 - 1 + r, x = c_x0 - 1 + px;
-        const bool ok = r < HR && rem < 4 * MO4 && px < PW && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;   // else padding / outside the image
-        rpk[n] = ok ? (unsigned)(r * W + x) << 2 | (unsigned)c : OOB;
+        const unsigned y = (unsigned)(c_y0 - 1) + r, x = (unsigned)(c_x0 - 1) + px;   // (wraps below 0: fails the unsigned bound)
+        const unsigned ok = slot_ok & (unsigned)(y < (unsigned)H) & (unsigned)(x < (unsigned)W);   // else padding / outside the image
+        rpk[n] = ok ? mad24(r, W, x) << 2 | c : OOB;   // (W < 2^20: the launcher checks)
       }
     }
   };
@@ -180,7 +202,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < IPW; ++n) rvoff[n] = rpk[n] == OOB ? OOB : (rpk[n] >> 2) * st4 + (rpk[n] & 3u) * 16u;
+      for (int n = 0; n < IPW; ++n) rvoff[n] = rpk[n] == OOB ? OOB : __umul24(rpk[n] >> 2, st4) + (rpk[n] & 3u) * 16u;   // (pixel index, pixel pitch < 2^24: the launcher)
     }
   };
   auto dma_piece = [&](int n, int stage) {   // request n of this wave's share of the cursor's super-chunk -> stage
@@ -238,11 +260,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   auto slab = [&](int kc) { return (unsigned)(((ct * nkc + (CHAIN ? (kc < nkc ? kc : kc - nkc) : (kc < nkc ? kc : nkc - 1))) * 4 + mu) * 6) * 1024u; };
   bf4 fbg[2][6];
 
-  f32x16 acc[6];
-#pragma unroll
-  for (int v = 0; v < 6; ++v)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
+  f32x16 acc[6];   // never cleared: the first MFMA of every plane in a tile's first chunk takes C = 0 (96 v_mov less in front of the K loop)
 
   // ---- fragments: lane (unit row ur, quad lq, K half) reads pixels 4 lq .. 4 lq + 5 of halo rows 2 ur + ra and 2 ur + rb --------
   const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
@@ -277,6 +295,13 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     return r;
   };
   auto add2 = [](f2 x, f2 y) -> f2 { f2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
+  auto mul2 = [](float k, f2 x) -> f2 {
+    f2 r;
+    const f2 kk = {k, k};
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "s"(kk), "v"(x));
+    return r;
+  };
+  auto max1 = [](float x, float y) -> float { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y)); return r; };
   auto sub2 = [](f2 x, f2 y) -> f2 { f2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y)); return r; };
   // F(4,3) B^T of channel pair q of the six pixels in d: 12 operations (v3 / v4 = t3 +- 2 (d3 - d1): the doubling is exact, so
   // fma(+-2, d3 - d1, t3) rounds the very sum conv_wino2d_r3_kernel formed with a multiplication and an addition)
@@ -372,8 +397,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const int step = 24 / cnt, at = cnt == 1 ? 13 : 5;
     return (g % step == at && g / step < cnt) ? g / step : -1;
   };
-  auto chunk = [&](int kc, auto h_c) {
+  auto chunk = [&](int kc, auto h_c, auto first_c) {
     constexpr int H = decltype(h_c)::value;
+    constexpr bool FIRST = decltype(first_c)::value != 0;   // the first chunk of a tile: its k = 0 MFMAs start the accumulators
     using RH = std::integral_constant<int, 1 - H>;
     const int rs = H == 0 ? st_s : st_n;   // stage of chunk kc + 1
     f2(&Ac)[6][2] = A[H];
@@ -400,7 +426,12 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       constexpr int g = decltype(g_c)::value;
       constexpr int jp = g >> 3, i8 = g & 7, k = i8 >> 1, j = 2 * jp + (i8 & 1);
       // A = weights (row = output channel), B = activations (column = unit): C^T of conv_wino2d_r3_kernel's tile, the same k-ordered sums
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k >> 1][k & 1], acc[j], 0, 0, 0);
+      if constexpr (FIRST && k == 0) {
+        const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k >> 1][k & 1], zero, 0, 0, 0);
+      } else {
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k >> 1][k & 1], acc[j], 0, 0, 0);
+      }
       if constexpr ((FLAGS & W2D_DBG_NOB) == 0) {
         if constexpr (k == 3) fbg[H][j] = conv_buf_load(brsrc, bvoff, so2 + (unsigned)j * 1024u);   // consumed: chunk kc + 2's slab into the same registers
       }
@@ -516,15 +547,20 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const float b0 = rawsum ? 0.f : p.bias[nrd], b1 = rawsum ? 0.f : p.bias[nrd + 1], b2 = rawsum ? 0.f : p.bias[nrd + 2], b3 = rawsum ? 0.f : p.bias[nrd + 3];
     const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
     const int ostr = rawsum ? p.Cout : p.ostride;
-    const bool act = p.leaky && !rawsum;
-    float* const orow = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + oy) * p.W + ox) * ostr + nrd;
+    const float slope = (p.leaky && !rawsum) ? 0.2f : 1.f;
+    // (the tile's corner in 64-bit SCALAR arithmetic, the thread's pixel inside the tile with 24-bit multiplies: the one 64-bit expression
+    // was six v_mul_lo_u32 + three v_mad_u64_u32, quarter rate, per pointer; 8 rows x W x the pixel pitch < 2^31: the launcher)
+    const int dyo = 2 * (run >> 3), dxo = 4 * (run & 7), nth = rng * 32 + rcg * 4;
+    float* const ocorner = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + y0) * p.W + x0) * ostr + n0;
+    float* const orow = ocorner + (__umul24(__umul24(dyo, p.W) + dxo, ostr) + nth);
     // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
     // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
     // Fused 1x1 convolution (ConvParams::pw_out; BN = Cout = 64): the activated tile goes to LDS as [pixel 256][68] behind the exchange
     // buffers instead of to `out` (68: 16-byte rows whose float4 pieces fall into 16 different bank groups for 16 consecutive pixels -
     // conflict-free ds_write_b128 from the (unit, channel group) threads and ds_read_b128 from the pixel threads); the 1x1 weights go
     // to LDS once as [c][4]; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
-    float* const pool_base = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.pool_ostride + nrd : nullptr;
+    float* const pool_corner = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1)) * p.pool_ostride + n0 : nullptr;
+    float* const pool_base = p.pool_out ? pool_corner + (__umul24(__umul24(dyo >> 1, p.W >> 1) + (dxo >> 1), p.pool_ostride) + nth) : nullptr;
     constexpr int PWS = 68;
     float* const pwt = smem + 2 * XB4 * 4;   // (never with W2D_F_CHAIN: the launcher refuses the fused 1x1 there)
     float* const pww = pwt + TH * PXW * PWS;   // [64][4]
@@ -541,13 +577,18 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       }
       __syncthreads();
       const bf4 m0 = xw[ridx], m1 = xw[ridx + 256], m2 = xw[ridx + 512], m3 = xw[ridx + 768];
+      // Packed, and without compare / select: max(v, slope v) is leaky_relu(0.2) for slope = 0.2 and v itself for slope = 1 (same bits as the
+      // v > 0 ? v : 0.2 v form, NaN and -0 included); 24 instead of 46 vector instructions per round (they are taken from the matrix pipe of
+      // the co-resident workgroup's K loop: profiles/r06_w2d_valu_diet.log)
       bf4 r0, r1;
   #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float bv = c == 0 ? b0 : c == 1 ? b1 : c == 2 ? b2 : b3;
-        float v0 = ((m0[c] + m1[c]) + m2[c]) + bv, v1 = ((m1[c] - m2[c]) - m3[c]) + bv;
-        if (act) { v0 = v0 > 0.f ? v0 : 0.2f * v0; v1 = v1 > 0.f ? v1 : 0.2f * v1; }
-        r0[c] = v0; r1[c] = v1;
+      for (int q = 0; q < 2; ++q) {
+        const f2 bq = q ? f2{b2, b3} : f2{b0, b1};
+        const f2 v0 = add2(add2(add2(pair_of(m0, q), pair_of(m1, q)), pair_of(m2, q)), bq);
+        const f2 v1 = add2(sub2(sub2(pair_of(m1, q), pair_of(m2, q)), pair_of(m3, q)), bq);
+        const f2 s0 = mul2(slope, v0), s1 = mul2(slope, v1);
+        set_pair(r0, q, f2{max1(v0[0], s0[0]), max1(v0[1], s0[1])});   // (asm: fmaxf on the results of asm statements costs two canonicalising
+        set_pair(r1, q, f2{max1(v1[0], s1[0]), max1(v1[1], s1[1])});   // v_max_f32 x, x, x more per element)
       }
       if (p.pw_out == nullptr) {
         if (ox + jx < p.W) {
@@ -605,14 +646,12 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       img = g / tpi;
       const int tr = g - img * tpi;
       y0 = (tr / ntx) * TH; x0 = (tr % ntx) * PXW;
-#pragma unroll
-      for (int v = 0; v < 6; ++v)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[v][r] = 0.f;
     }
-    for (int kc = kc0; kc < kc1; kc += 2) {
-      chunk(kc, C0{});
-      chunk(kc + 1, C1{});
+    chunk(kc0, C0{}, C1{});
+    chunk(kc0 + 1, C1{}, C0{});
+    for (int kc = kc0 + 2; kc < kc1; kc += 2) {
+      chunk(kc, C0{}, C0{});
+      chunk(kc + 1, C1{}, C0{});
     }
     if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { if (ti + 1 == nt) tm2 = __builtin_readcyclecounter(); }
     epilogue();
@@ -657,14 +696,21 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
     if (BN != 64 || p.Cout != 64 || p.pool_out || p.pw_cout < 1 || p.pw_cout > 4) return hipErrorInvalidValue;
   } else if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
   if (p.pool_out && ((p.H | p.W) & 1 || p.pool_ostride % 4 || (reinterpret_cast<uintptr_t>(p.pool_out) & 15))) return hipErrorInvalidValue;
+  if (p.W <= 0 || p.H <= 0 || p.W >= (1 << 20) || p.ostride >= (1 << 22) || p.pool_ostride >= (1 << 22) || p.Cout >= (1 << 22) ||
+      (long long)8 * p.W * (p.ostride > p.Cout ? p.ostride : p.Cout) >= (1ll << 31)) return hipErrorInvalidValue;   // 24-bit multiplies of the DMA offsets: 10 halo rows x W pixels < 2^24
   for (int i = 0; i < p.nseg; ++i)
-    if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
+    if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].stride <= 0 || p.seg[i].stride >= (1 << 22) || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
   auto kern = conv_wino2d_kernel<BN, FLAGS, NS>;
   static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
   if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, 144 * 1024); e != hipSuccess) return e;
   const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
   const int ntiles = p.NB * ntx * nty, chain = CHAIN ? p.chain : 1;
   dim3 grid((unsigned)((ntiles + chain - 1) / chain), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
-  hipLaunchKernelGGL(kern, grid, dim3(NT), lds + (size_t)conv_wino2d_debug_extra_lds(), s, p);
+  ConvParams q = p;   // + the reciprocals of the workgroup decomposition: ceil(2^32 / d), exact for x d < 2^32 (else 0 = divide)
+  auto magic = [](unsigned long long d, unsigned long long xmax) -> unsigned { return (d <= 1 || xmax * d >= (1ull << 32)) ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+  q.mg_nby = magic(grid.y, (unsigned long long)grid.x * grid.y);
+  q.mg_tpi = magic((unsigned long long)ntx * nty, (unsigned long long)ntiles + chain);
+  q.mg_ntx = magic(ntx, (unsigned long long)ntx * nty);
+  hipLaunchKernelGGL(kern, grid, dim3(NT), lds + (size_t)conv_wino2d_debug_extra_lds(), s, q);
   return hipGetLastError();
 }

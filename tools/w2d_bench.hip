@@ -160,6 +160,7 @@ static Variant variants[] = {
     {"w2d 32 ns2 plain", 32, 1, conv_wino2d_launch<32, 4, 2>},
     {"w2d 32 ns2 lds+24", 32, 1, w2d_ns2_lds<24>}, {"w2d 32 ns2 lds+30", 32, 1, w2d_ns2_lds<30>}, {"w2d 32 ns2 lds+32", 32, 1, w2d_ns2_lds<32>},
     W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
+    {"w2d 32 ns2 time", 32, -1, conv_wino2d_launch<32, 4 | W2D_DBG_TIME, 2>},
     {"w2d 32 ns2 ch4 time", 32, -1, w2d_chain<32, 2, 4, W2D_DBG_TIME>}, {"w2d 64 ns3 ch4 time", 64, -1, w2d_chain<64, 3, 4, W2D_DBG_TIME>},
     W2N("64 abl-noxf", 64, 4 | W2D_DBG_NOXF), W2N("32 abl-noxf", 32, 4 | W2D_DBG_NOXF),
     W2N("64 abl-nodma", 64, 4 | W2D_DBG_NODMA), W2N("32 abl-nodma", 32, 4 | W2D_DBG_NODMA),
