@@ -46,7 +46,10 @@
 #pragma once
 #include "conv_buf_impl.h"
 
-enum { W2D_F_CHAIN = 64,       // a workgroup walks ConvParams::chain consecutive pixel tiles (same output channels): the DMA cursor and the weight
+enum { W2D_F_SQ = 128,         // the 32 units of a tile as 8 unit rows x 4 units = 16 x 16 pixels instead of 4 x 8 = 8 rows x 32 pixels: levels whose width is
+                               // a multiple of 16 but not of 32 (144x240: 7.5 tiles per row, 6.25 % of the MFMA columns masked) tile exactly.  18 halo rows of 18
+                               // pixels (row pitch 82 slots) fill the same 24 requests per stage.  Same sums, same bits.
+       W2D_F_CHAIN = 64,       // a workgroup walks ConvParams::chain consecutive pixel tiles (same output channels): the DMA cursor and the weight
                                // requests run on into the next tile while this one finishes, the epilogue's exchange buffers lie BEHIND the stages
                                // (see "chained tiles" below).  Same sums, same bits.
        W2D_F_XFIRST = 32,      // tools only: x transform per row, then the y combine (120 VALU per chunk; the bits of conv_wino2d_r3_kernel)
@@ -67,27 +70,28 @@ __device__ __forceinline__ void w2d_for_each(F&& f, std::integer_sequence<int, G
 // BN = 32 NG output channels per workgroup, one wave per (mu, 32 channels): 4 NG waves, two waves per SIMD either way (BN = 64: one
 // workgroup of 8 waves per CU; BN = 32: two of 4 - their prologues / epilogues overlap the other's K loop: the usual winner)
 // the multiply-shift quotients of the DMA slot decomposition (slot / 148, rest / 36, rest / 9) are exact on the ranges they are used on
-constexpr bool w2d_slot_quotients_exact() {
-  for (unsigned s = 0; s < 1536u; ++s) if (((s * 443u) >> 16) != s / 148u) return false;
-  for (unsigned s = 0; s < 148u; ++s) if (((s * 1821u) >> 16) != s / 36u) return false;
-  for (unsigned s = 0; s < 36u; ++s) if (((s * 7282u) >> 16) != s / 9u) return false;
-  return true;
+constexpr unsigned w2d_magic20(unsigned d) { return ((1u << 20) + d - 1u) / d; }
+constexpr bool w2d_quotient_exact(unsigned d, unsigned n) {   // (x * magic) >> 20 == x / d for x < n; 24-bit operands, a product below 2^32
+  for (unsigned x = 0; x < n; ++x) if (((x * w2d_magic20(d)) >> 20) != x / d) return false;
+  return n < (1u << 12) && w2d_magic20(d) < (1u << 20);
 }
-static_assert(w2d_slot_quotients_exact(), "slot quotients");
 
 template <int BN, int FLAGS, int NS_ = 3>
 __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_wino2d_kernel(ConvParams p) {
-  constexpr int QW = 8, TH = 8, HR = TH + 2, PXW = 4 * QW, PW = PXW + 2;
+  constexpr bool SQ = (FLAGS & W2D_F_SQ) != 0;
+  constexpr int QW = SQ ? 4 : 8, TH = SQ ? 16 : 8, HR = TH + 2, PXW = 4 * QW, PW = PXW + 2;   // units per tile row; tile rows; halo rows; tile / halo pixels per row
+  static_assert(QW * (TH / 2) == 32, "32 units per tile");
   constexpr int NG = BN / 32, NW = 4 * NG;
-  constexpr int RP4 = 148, MO4 = 36, CO4 = 9;   // row pitch, m stride, piece stride in 16-byte slots (2368, 576, 144 bytes)
-  constexpr int NREQ = 24;                      // DMA requests (1 KB each) per stage: 10 rows x 148 slots = 1480 <= 1536
+  constexpr int CO4 = (PW + 3) / 4, MO4 = 4 * CO4, RP4 = 4 * MO4 + (SQ ? 2 : 4);   // piece stride, m stride, row pitch in 16-byte slots (8 x 32: 144, 576, 2368 bytes;
+                                                                                    // 16 x 16: 80, 320, 1312 bytes - two halo rows down is 2624 = 64 (mod 256) bytes away)
+  constexpr int NREQ = 24;                      // DMA requests (1 KB each) per stage: 10 rows x 148 slots = 1480, 18 rows x 82 slots = 1476 <= 1536
   constexpr int STAGE4 = NREQ * 64;             // slots per stage
   constexpr int NS = NS_;                       // stages (3; the chained 32-channel tile: 2, so that two workgroups with their exchange buffers fit a CU)
   constexpr bool CHAIN = (FLAGS & W2D_F_CHAIN) != 0;
   static_assert(NS == 2 || NS == 3, "stages");
   constexpr int IPW = NREQ / NW;                // requests per wave and super-chunk
   static_assert(NREQ % NW == 0, "requests per wave");
-  static_assert(RP4 == 148 && MO4 == 36 && CO4 == 9 && NREQ * 64 <= 1536, "the slot quotients below are made for this layout");
+  static_assert(w2d_quotient_exact(RP4, NREQ * 64) && w2d_quotient_exact(MO4, RP4) && w2d_quotient_exact(CO4, MO4), "slot quotients");
   static_assert(HR * RP4 <= STAGE4, "stage size");
   constexpr bool XF = (FLAGS & W2D_F_XFIRST) != 0;
   constexpr unsigned OOB = 0xFFFFFFFFu;
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // segment set-up forms the offsets from it and the cursor's tile - behind an opaque copy, or hipcc hoists the unpacked fields out
   // of the tile loop (18 registers, spilled, reloaded with s_waitcnt vmcnt(0) in the middle of the K loop).
   unsigned rpk[IPW];
-  auto quot16 = [](unsigned x, unsigned magic) -> unsigned { unsigned q; asm("v_mul_u32_u24 %0, %1, %2\n\tv_lshrrev_b32 %0, 16, %0" : "=v"(q) : "v"(x), "s"(magic)); return q; };
+  auto quot20 = [](unsigned x, unsigned magic) -> unsigned { unsigned q; asm("v_mul_u32_u24 %0, %1, %2\n\tv_lshrrev_b32 %0, 20, %0" : "=v"(q) : "v"(x), "s"(magic)); return q; };
   auto mad24 = [](unsigned a, int b, unsigned c) -> unsigned { unsigned q; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(q) : "v"(a), "s"(b), "v"(c)); return q; };
   auto set_rpk = [&]() {   // for the cursor's tile (chained: tile independent, called once)
     const int H = p.H, W = p.W;
@@ -166,9 +170,9 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       // (24-bit forms spelled out: hipcc does not know that a slot number is small and emits the quarter-rate v_mul_lo_u32 / v_mad_u64_u32 -
       // every vector instruction of a prologue is taken from the co-resident workgroup's matrix pipe)
       const unsigned sl = 64u * (unsigned)(wv + NW * n) + (unsigned)lane;
-      const unsigned r = quot16(sl, 443u), rem = mad24(r, -RP4, sl);
-      const unsigned m = quot16(rem, 1821u), rr = mad24(m, -MO4, rem);
-      const unsigned c = quot16(rr, 7282u), k = mad24(c, -CO4, rr);
+      const unsigned r = quot20(sl, w2d_magic20(RP4)), rem = mad24(r, -RP4, sl);
+      const unsigned m = quot20(rem, w2d_magic20(MO4)), rr = mad24(m, -MO4, rem);
+      const unsigned c = quot20(rr, w2d_magic20(CO4)), k = mad24(c, -CO4, rr);
       const unsigned px = 4u * k + m;
       const unsigned slot_ok = (unsigned)(r < (unsigned)HR) & (unsigned)(rem < 4u * MO4) & (unsigned)(px < (unsigned)PW);
       if constexpr (CHAIN) {
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
 
   // ---- fragments: lane (unit row ur, quad lq, K half) reads pixels 4 lq .. 4 lq + 5 of halo rows 2 ur + ra and 2 ur + rb --------
   const bf4* const smem4 = reinterpret_cast<const bf4*>(smem);
-  const int ur = l31 >> 3, lq = l31 & 7;
+  const int ur = l31 / QW, lq = l31 % QW;
   const int ra = mu == 0 ? 0 : mu == 2 ? 2 : 1, rb = mu == 0 ? 2 : mu == 1 ? 2 : mu == 2 ? 1 : 3;
   const float sgn = mu == 1 ? 1.f : -1.f;
   const int ix_a = (2 * ur + ra) * RP4 + half * CO4 + lq, ix_b = (2 * ur + rb) * RP4 + half * CO4 + lq;
@@ -545,12 +549,12 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const int nrd = n0 + rng * 32 + rcg * 4;
     const bool rawsum = ksp > 1;   // split-K: no bias, no activation, [split][pixel][Cout]
     const float b0 = rawsum ? 0.f : p.bias[nrd], b1 = rawsum ? 0.f : p.bias[nrd + 1], b2 = rawsum ? 0.f : p.bias[nrd + 2], b3 = rawsum ? 0.f : p.bias[nrd + 3];
-    const int oy = y0 + 2 * (run >> 3), ox = x0 + 4 * (run & 7);
+    const int oy = y0 + 2 * (run / QW), ox = x0 + 4 * (run % QW);
     const int ostr = rawsum ? p.Cout : p.ostride;
     const float slope = (p.leaky && !rawsum) ? 0.2f : 1.f;
     // (the tile's corner in 64-bit SCALAR arithmetic, the thread's pixel inside the tile with 24-bit multiplies: the one 64-bit expression
     // was six v_mul_lo_u32 + three v_mad_u64_u32, quarter rate, per pointer; 8 rows x W x the pixel pitch < 2^31: the launcher)
-    const int dyo = 2 * (run >> 3), dxo = 4 * (run & 7), nth = rng * 32 + rcg * 4;
+    const int dyo = 2 * (run / QW), dxo = 4 * (run % QW), nth = rng * 32 + rcg * 4;
     float* const ocorner = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + y0) * p.W + x0) * ostr + n0;
     float* const orow = ocorner + (__umul24(__umul24(dyo, p.W) + dxo, ostr) + nth);
     // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
@@ -607,7 +611,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
           }
         }
       } else {
-        float* const tr = pwt + ((2 * (run >> 3)) * PXW + 4 * (run & 7) + jx) * PWS + rng * 32 + rcg * 4;
+        float* const tr = pwt + ((2 * (run / QW)) * PXW + 4 * (run % QW) + jx) * PWS + rng * 32 + rcg * 4;
         *reinterpret_cast<bf4*>(tr) = r0;
         *reinterpret_cast<bf4*>(tr + PXW * PWS) = r1;
       }
@@ -703,7 +707,8 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   auto kern = conv_wino2d_kernel<BN, FLAGS, NS>;
   static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
   if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, 144 * 1024); e != hipSuccess) return e;
-  const int ntx = (p.W + 31) / 32, nty = (p.H + 7) / 8;
+  constexpr bool SQ = (FLAGS & W2D_F_SQ) != 0;
+  const int ntx = SQ ? (p.W + 15) / 16 : (p.W + 31) / 32, nty = SQ ? (p.H + 15) / 16 : (p.H + 7) / 8;
   const int ntiles = p.NB * ntx * nty, chain = CHAIN ? p.chain : 1;
   dim3 grid((unsigned)((ntiles + chain - 1) / chain), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
   ConvParams q = p;   // + the reciprocals of the workgroup decomposition: ceil(2^32 / d), exact for x d < 2^32 (else 0 = divide)

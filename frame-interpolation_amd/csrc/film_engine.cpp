@@ -168,9 +168,18 @@ std::vector<int> wino43_candidates(int Cout, bool pool = false, bool pw = false)
   return out;
 }
 
-std::vector<int> wino2d_candidates(int Cout, bool pw = false) {
+// (H, W: the level.  The square arrangement is a candidate where its tiles pad the level no more than the 8 x 32 ones.)
+std::vector<int> wino2d_candidates(int Cout, bool pw, int H, int W) {
+  const int64_t pad_r = (int64_t)((W + 31) / 32) * ((H + 7) / 8), pad_s = (int64_t)((W + 15) / 16) * ((H + 15) / 16);
+  const bool sq = pad_s <= pad_r;
+  std::vector<int> shapes;
+  if (pw || Cout % 64 == 0) { shapes.push_back(W2D_8x64); if (sq) shapes.push_back(W2D_16x64); }
+  if (!pw) {   // (the fused 1x1 needs every channel of a pixel in one workgroup)
+    shapes.push_back(W2D_8x32); shapes.push_back(W2D_8x32_S2);
+    if (sq) { shapes.push_back(W2D_16x32); shapes.push_back(W2D_16x32_S2); }
+  }
   std::vector<int> out;
-  for (int sh : (pw ? std::vector<int>{W2D_8x64} /* the fused 1x1 needs every channel of a pixel in one workgroup */ : Cout % 64 == 0 ? std::vector<int>{W2D_8x64, W2D_8x32, W2D_8x32_S2} : std::vector<int>{W2D_8x32, W2D_8x32_S2})) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
+  for (int sh : shapes) { out.push_back(sh | CONV_TILE_W2D); out.push_back(sh | CONV_TILE_W2D | CONV_TILE_XCD); }
   return out;
 }
 
@@ -226,7 +235,7 @@ hipError_t launch_op(const OpDesc& op, float* arena, const float* wts, hipStream
 // its Cout (random activations, the real weights) and keeps the fastest.  The choice cannot change the
 // results: every output element is the same k-ordered fma chain whatever the tile.
 std::vector<int> conv_candidates(const OpDesc& op) {
-  std::vector<int> cands = op.fold == 3 ? fold4_candidates(op.Cout) : (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, op.pw_out.buf >= 0) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
+  std::vector<int> cands = op.fold == 3 ? fold4_candidates(op.Cout) : (op.fold == 2 && op.split == 2) ? foldx3_candidates(op.Cout) : op.wino == 4 ? wino2d_candidates(op.Cout, op.pw_out.buf >= 0, op.H, op.W) : op.wino == 3 ? wino43_candidates(op.Cout, op.out2.buf >= 0, op.pw_out.buf >= 0) : op.wino == 2 ? winox3_candidates(op.Cout) : op.wino ? wino_candidates(op.Cout) : op.split ? split_candidates(op.Cout, op.split == 2) : op.halo ? halo_candidates(op.Cout) : tile_candidates(op.Cout);
   if (op.c3) {   // the 3-channel first layer has one kernel (conv_c3_kernel)
     cands.clear();
     cands.push_back(TILE_C3_DIRECT | CONV_TILE_C3);
@@ -303,11 +312,11 @@ int autotune_plan(film_t* h, Plan* P) {
         if (timed[c].first < best_ms) { best_ms = timed[c].first; best = timed[c].second; }
       // conv_wino2d_kernel: a 64-channel tile within 2 % of the fastest wins - it reads its input patch half as often (45.2 -> 40.2
       // GB of fabric reads per 1080p forward with the tile forced, same step time: profiles/r04_w2d_tile64_ab.log)
-      if (op.wino == 4 && (best & 15) != W2D_8x64) {
+      if (op.wino == 4 && !film_w2d_64(best & 15)) {
         float ms64 = 1e30f;
         int t64 = -1;
         for (size_t c = 0; c < std::max<size_t>(nfin, 1) && c < timed.size(); ++c)
-          if ((timed[c].second & 15) == W2D_8x64 && timed[c].first < ms64) { ms64 = timed[c].first; t64 = timed[c].second; }
+          if (film_w2d_64(timed[c].second & 15) && timed[c].first < ms64) { ms64 = timed[c].first; t64 = timed[c].second; }
         if (t64 >= 0 && ms64 <= best_ms * 1.02f) best = t64;
       }
       h->tune_cache[sig] = best;

@@ -248,7 +248,12 @@ static inline bool film_w43_shape_built(int sh) {
 // 64 channels = 8 waves (one workgroup per CU), 32 channels = 4 waves (two per CU).  Same sums: the autotuner picks freely.
 // W2D_8x32_S2 (round 6): the 32-channel tile on TWO DMA stages instead of three (48 KB of LDS; all requests of a super-chunk in the gaps of ONE
 // chunk, one super-chunk less requested in the prologue): 4-15 % faster on every layer with K <= 208, equal above (profiles/r06_w2d_chain_ns2.log).
-enum Wino2dTile { W2D_8x64 = 0, W2D_8x32 = 1, W2D_8x32_S2 = 2, W2D_SHAPES = 3 };
+// W2D_16x* (round 6): the 32 units as 8 unit rows x 4 units = 16 x 16 pixels (W2D_F_SQ, conv_wino2d_impl.h).  Offered where it pads a level no more than the 8 x 32
+// arrangement: a 144x240 level tiles exactly (8 x 32: 7.5 tiles per row) - 5-7.5 % faster there, and the autotuner also picks it on some exact-fit levels
+// (profiles/r06_w2d_square_tile.log).
+enum Wino2dTile { W2D_8x64 = 0, W2D_8x32 = 1, W2D_8x32_S2 = 2, W2D_16x64 = 3, W2D_16x32 = 4, W2D_16x32_S2 = 5, W2D_SHAPES = 6 };
+inline bool film_w2d_square(int shape) { return shape >= W2D_16x64 && shape <= W2D_16x32_S2; }
+inline bool film_w2d_64(int shape) { return shape == W2D_8x64 || shape == W2D_16x64; }
 // conv_fold4_kernel tiles (CONV_TILE_FOLD4): 4 rows x 32 low-resolution pixels x output channels; four waves side by side, each 4 x 8 pixels
 // x all channels of the tile.  64 channels: 235 VGPRs, two workgroups per CU; 32 channels: 139 VGPRs, three.  Same sums.
 enum Fold4Tile { F4_4x64 = 0, F4_4x32 = 1 };

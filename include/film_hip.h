@@ -211,7 +211,7 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *                  (which also switches it off); factor from the level size and the layer only.  Drops the cached plans.
  *   "w43_shape" n  test knob: every convolution on conv_wino43_kernel that can run tile shape n (Wino43Tile, film_kernels.h)
  *                  does, instead of the autotuned shape; -1 (default) = autotuned.  Results cannot change.  Drops the cached plans.
- *   "w2d_shape" n  the same for conv_wino2d_kernel (Wino2dTile).
+ *   "w2d_shape" n  the same for conv_wino2d_kernel (Wino2dTile: 0..2 = 8 rows x 32 pixels, 3..5 = 16 x 16 pixels - the latter only on levels it pads no more).
  *   "fold4_shape" n  the same for conv_fold4_kernel (Fold4Tile).
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in limits: 64 GiB of
  *                  workspace, 4 GiB per buffer read through a whole-buffer 32-bit offset); frame pairs are independent,

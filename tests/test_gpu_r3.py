@@ -370,7 +370,8 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
     got, _ = _check_stages(eng, opt, wts, x0, x1)
     taps = {k: eng.tap(k) for k in ('feat1', 'aligned0', 'aligned1')}
     used = set()
-    for shape in range(3):        # Wino2dTile: 0 = 64 channels per workgroup (8 waves), 1 = 32 (4 waves, two workgroups per CU), 2 = 32 on two DMA stages
+    for shape in range(6):        # Wino2dTile: 0 = 64 channels per workgroup (8 waves), 1 = 32 (4 waves, two workgroups per CU), 2 = 32 on two DMA stages;
+                                  # 3..5 = the same on the 16 x 16-pixel arrangement of the 32 units (offered on levels it pads no more than 8 x 32)
         eng.set_option('w2d_shape', shape)
         tiles = {o['tile'] & 15 for o in eng.plan(b, h, w)['ops'] if o['kind'] == 'conv_mfma' and (o['tile'] & 8192)}
         if shape not in tiles:
@@ -381,7 +382,7 @@ def test_nested_winograd_kernel_on_every_level(published, b, h, w):
         for k, v in taps.items():
             assert np.array_equal(eng.tap(k), v), (shape, k)
     print('nested-Winograd tile shapes exercised:', sorted(used))
-    assert {0, 1, 2} <= used, used
+    assert {0, 1, 2, 3, 4, 5} <= used, used
     eng.set_option('w2d_shape', -1)
     eng.set_option('wino2d', 0)
     assert sum(1 for op in eng.plan(b, h, w)['ops'] if op.get('wino') == 4) == 0
