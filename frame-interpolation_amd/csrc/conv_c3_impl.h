@@ -89,15 +89,22 @@ __global__ __launch_bounds__(256) void conv_c3_kernel(ConvParams p) {
     for (int s = 0; s < 14; ++s)
 #pragma unroll
       for (int nt = 0; nt < TN; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[s], wb[nt][s], acc[nt], 0, 0, 0);
-    const size_t rowbase = ((size_t)img * p.H + y) * p.W;
+    // Stores: buffer stores from a SCALAR row corner (image, row y, first pixel x0, first channel) + one per-lane offset + a scalar
+    // offset per accumulator register; pixels past the row end fall outside the resource's size and are dropped by the bounds check.
+    // (Round 6: sixteen 64-bit pointers in registers and a branch per store made this 176 VGPRs = two waves per SIMD.)
+    const int npx = p.W - x0 < 32 ? p.W - x0 : 32;
+    float* const corner = p.out + (((size_t)img * p.H + y) * p.W + x0) * p.ostride + nb0;
+    const conv_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(corner, 0, (int)((unsigned)npx * (unsigned)p.ostride * 4u), 0x00020000);
+    const unsigned pitch = (unsigned)p.ostride * 4u;
+    const unsigned ovoff = (unsigned)(4 * half) * pitch + (unsigned)l31 * 4u;
+    const float slope = p.leaky ? 0.2f : 1.f;   // max(v, slope v): leaky_relu(0.2) or v, the bits of the compare-and-select form
 #pragma unroll
     for (int nt = 0; nt < TN; ++nt)
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
-        const int m = (q & 3) + 8 * (q >> 2) + 4 * half;
-        float v = acc[nt][q] + bias[nt];
-        if (p.leaky) v = v > 0.f ? v : 0.2f * v;
-        if (x0 + m < p.W) p.out[(rowbase + x0 + m) * p.ostride + nb0 + nt * 32 + l31] = v;
+        const int m = (q & 3) + 8 * (q >> 2);   // + 4 half: in ovoff
+        const float v = acc[nt][q] + bias[nt];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, __builtin_fmaxf(v, slope * v)), orsrc, (int)(ovoff + (unsigned)(nt * 128)), (int)((unsigned)m * pitch), 0);
       }
 #pragma unroll
     for (int s = 0; s < 14; ++s) a_cur[s] = a_nxt[s];
