@@ -705,8 +705,12 @@ def main():
             hm = float(np.median(t_h))
             extra['host_buffers'] = {'ms_per_step': round(hm, 3), 'frames_per_s': round(frames_per_step / (hm * 1e-3), 4),
                                      'h2d_ms': round(h2d, 3), 'd2h_ms': round(d2h, 3), 'bytes_in': int(2 * x0h.nbytes), 'bytes_out': int(x0h.nbytes),
-                                     'note': 'numpy -> numpy through film_interpolate(FILM_MEM_HOST), pageable host memory; h2d / d2h: the same bytes '
-                                             'from / to pinned memory on their own; the headline `value` keeps the frames resident in HBM'}
+                                     'over_device_resident_ms': round(hm - dt / args.steps * 1e3, 3),
+                                     'note': 'numpy -> numpy through film_interpolate(FILM_MEM_HOST), pageable host memory, the reference interface '
+                                             '(eval/interpolator.py:152-209); the call pipelines its copies: second frame uploaded behind the first '
+                                             'frame\'s first layers, first half of the result downloaded behind the second half\'s last layer (option '
+                                             'host_overlap); h2d / d2h: the same bytes from / to pinned memory on their own; the headline `value` '
+                                             'keeps the frames resident in HBM'}
         value = (1 if strong else reported) * args.steps * frames_per_step / dt
         result = {
             'metric': METRIC.get(args.workload, 'interpolated frames/sec @1080p'), 'value': round(value, 4), 'unit': 'frames/s',

@@ -513,6 +513,7 @@ void film_destroy(film_t* h) {
   if (h->packed_dev) (void)hipFree(h->packed_dev);
   if (h->stage) (void)hipFree(h->stage);
   if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipEvent_t& e : h->pipe_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (h->stream2) (void)hipStreamDestroy(h->stream2);
   delete h;
 }
@@ -528,6 +529,7 @@ int film_set_option(film_t* h, const char* key, int64_t value) {
   else if (!strcmp(key, "profile")) h->opt_profile = value != 0;
   else if (!strcmp(key, "autotune")) h->opt_autotune = value != 0;
   else if (!strcmp(key, "max_batch")) h->opt_max_batch = value > 0 ? (int)value : 0;
+  else if (!strcmp(key, "host_overlap")) h->opt_host_overlap = value != 0;
   else if (!strcmp(key, "tune_ms")) h->opt_tune_ms = value > 0 ? (int)value : 0;
   else if (!strcmp(key, "splitk")) {
     if ((value != 0) != (h->opt_splitk != 0)) {  // plans carry the op list: drop them
@@ -815,6 +817,10 @@ int film_forward(film_t* h, const float* x0, const float* x1, int B, int H, int 
   return FILM_OK;
 }
 
+namespace {
+int interpolate_host_pipeline(film_t* h, Plan* P, TileMapParams tp, const float* x0, const float* x1, float* out, float* st, size_t frame_bytes, hipStream_t s);
+}
+
 int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, int W, int align, int block_h,
                      int block_w, float* out, int mem_kind, void* stream) {
   if (!h || !x0 || !x1 || !out) return fail(h, FILM_ERR_INVALID, "NULL argument");
@@ -854,9 +860,16 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
     }
     float* st = (float*)h->stage;
     const size_t nf = frame_bytes / sizeof(float);
+    d0 = st; d1 = st + nf; dout = st + 2 * nf;
+    // Host pipeline (round 6): one chunk on the direct two-lane executor - see interpolate_host_pipeline below
+    if (h->opt_host_overlap && !h->opt_profile && h->opt_graph == 2 && h->opt_lanes != 0 && ntiles <= tmax && h->stream2) {
+      Plan* P = nullptr;
+      rc = get_plan(h, ntiles, tp.TH, tp.TW, true, &P);
+      if (rc == FILM_OK) return interpolate_host_pipeline(h, P, tp, x0, x1, out, st, frame_bytes, s);
+      if (rc != FILM_ERR_NOMEM) return rc;   // (workspace did not fit: the chunked path below)
+    }
     HIPCHK(h, hipMemcpyAsync(st, x0, frame_bytes, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(st + nf, x1, frame_bytes, hipMemcpyHostToDevice, s));
-    d0 = st; d1 = st + nf; dout = st + 2 * nf;
   }
   int chunk = balanced_chunk(ntiles, tmax);
   for (int t0 = 0; t0 < ntiles;) {
@@ -886,12 +899,38 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
 }
 
 namespace {
+// ---- batch parts of an op (the overlapped host path of film_interpolate) --------------------------------------------------------
+// A convolution whose input is ONE segment without a batch remap computes every image of its batch independently: images
+// [part * NB / nparts, (part + 1) * NB / nparts) as a launch of their own give the same bits (the kernel family and the tile are the op's).
+bool batch_splittable(const OpDesc& op, int nparts) {
+  return op.kind == OP_CONV && op.nseg == 1 && op.seg[0].bmod == 0 && op.seg[0].boff == 0 && op.seg[0].up == 0 && op.ksplit <= 1 && op.fold == 0 &&
+         op.NB >= nparts && op.NB % nparts == 0 && (op.out2.buf < 0 || (!(op.H & 1) && !(op.W & 1)));
+}
+OpDesc batch_part(const OpDesc& op, int part, int nparts) {
+  OpDesc q = op;
+  q.NB = op.NB / nparts;
+  const int64_t px = (int64_t)part * q.NB * op.H * op.W;
+  q.seg[0].v.off += px * op.seg[0].v.stride;
+  q.out.off += px * op.out.stride;
+  if (op.out2.buf >= 0) q.out2.off += (int64_t)part * q.NB * (op.H / 2) * (op.W / 2) * op.out2.stride;
+  if (op.pw_out.buf >= 0) q.pw_out.off += px * op.pw_out.stride;
+  return q;
+}
+// Hooks of film_interpolate's host-buffer pipeline into the two-lane issue (see there): `head` = the leading main-lane convolutions that run per
+// input frame (part 0 = the tiles of x0 - launched by the caller BEFORE the second frame's upload; issue_lanes launches part 1), `tail` = the
+// last op (the decoder's last layer + RGB head) runs as two tile halves with `mid_tail` between them (stitch + download of the first half).
+struct LanePipe {
+  std::vector<size_t> head;
+  bool tail = false;
+  std::function<hipError_t()> mid_tail;
+};
+
 // The plan's ops on two lanes: lane 0 on `main`, lane 1 (small subtrees, coarse flow levels, the t = 0.5 warps) on the handle's side
 // stream, forked from and joined to `main`; cross-lane ordering = the events found by Planner::analyze_lanes (each op is waited for
 // at most once by the other lane - see there for why that matters to a graph replay).  Called inside a stream capture (graph = 1:
 // the events become graph edges) or directly (graph = 2: real events; one set per plan, re-recorded every forward - a wait refers
 // to the record that precedes it in program order, and everything of forward n + 1 is ordered behind forward n's join on `main`).
-hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main, bool capturing) {
+hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main, bool capturing, const LanePipe* lp = nullptr) {
   const size_t nops = P->ops.size();
   if (P->lane_ev.size() < nops + 2) P->lane_ev.resize(nops + 2, nullptr);
   hipError_t ev_err = hipSuccess;
@@ -917,7 +956,13 @@ hipError_t issue_lanes(film_t* h, Plan* P, hipStream_t main, bool capturing) {
         le = hipStreamWaitEvent(ls, event_of((size_t)d), 0);
         if (le != hipSuccess) break;
       }
-    if (le == hipSuccess) le = launch_op(op, P->arena, h->packed_dev, ls);
+    if (le != hipSuccess) break;
+    if (lp && std::find(lp->head.begin(), lp->head.end(), i) != lp->head.end()) le = launch_op(batch_part(op, 1, 2), P->arena, h->packed_dev, ls);
+    else if (lp && lp->tail && i + 1 == nops) {
+      le = launch_op(batch_part(op, 0, 2), P->arena, h->packed_dev, ls);
+      if (le == hipSuccess) le = lp->mid_tail();
+      if (le == hipSuccess) le = launch_op(batch_part(op, 1, 2), P->arena, h->packed_dev, ls);
+    } else le = launch_op(op, P->arena, h->packed_dev, ls);
     if (le == hipSuccess && two_lanes && op.signal) le = hipEventRecord(event_of(i), ls);
   }
   if (two_lanes && le == hipSuccess) {
@@ -986,6 +1031,74 @@ int run_plan(film_t* h, Plan* P, hipStream_t s) {
     for (const OpDesc& op : P->ops) HIPCHK(h, launch_op(op, P->arena, h->packed_dev, s));
   }
   h->last_plan = P;
+  return FILM_OK;
+}
+
+// film_interpolate with HOST buffers, one chunk, direct two-lane executor.  The reference's call is numpy -> numpy (eval/interpolator.py:152-209): the
+// copies are part of it.  Instead of upload, upload, work, download:
+//   main stream:  H2D x0 | tiles of x0 | first layers on x0's tiles ("head" parts 0) | wait E0 | the same layers on x1's tiles | ... the plan ... |
+//                 last layer, first tile half | stitch first half, record E1 | last layer, second half | stitch | D2H second half
+//   side stream:  (behind the tiles of x0) H2D x1 | tiles of x1 | record E0 | lane 1 of the plan ... | wait E1 | D2H first half
+// The API calls are made in this order, so that it also holds for pageable memory, whose copies block the calling thread: the GPU works on x0
+// while the host copies x1, and on the second half of the last layer while the host receives the first half of the frame.
+// Splitting a convolution's batch into two launches cannot change a bit (batch_part).
+int interpolate_host_pipeline(film_t* h, Plan* P, TileMapParams tp, const float* x0, const float* x1, float* out, float* st, size_t frame_bytes, hipStream_t s) {
+  const int nt = P->B;
+  const size_t nf = frame_bytes / sizeof(float);
+  for (hipEvent_t& e : h->pipe_ev)
+    if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  const Buffer& img0 = P->bufs[P->find("img0")];
+  const Buffer& ob = P->bufs[P->find("out")];
+  LanePipe lp;
+  for (size_t i = 0; i < P->ops.size() && lp.head.size() < 2; ++i) {   // the leading main-lane convolutions that read nothing from the side lane
+    const OpDesc& op = P->ops[i];
+    if (op.lane == 1) continue;
+    if (!batch_splittable(op, 2) || !op.xdeps.empty() || op.NB != 2 * nt) break;
+    lp.head.push_back(i);
+  }
+  const OpDesc& last = P->ops.back();
+  // the tiles of a frame are row-major blocks: the first half of the tiles = the upper half of the frame when there is one frame and an even
+  // number of block rows
+  lp.tail = tp.B == 1 && tp.bh % 2 == 0 && last.lane == 0 && last.pw_out.buf >= 0 && last.NB == nt && batch_splittable(last, 2) && P->ops.size() > lp.head.size() + 1 &&
+            std::find(lp.head.begin(), lp.head.end(), P->ops.size() - 1) == lp.head.end();
+  tp.tile0 = 0;
+  lp.mid_tail = [&]() -> hipError_t {
+    TileMapParams t2 = tp;
+    t2.ntiles = nt / 2; t2.src = P->arena + ob.off; t2.dst = st + 2 * nf;
+    hipError_t e = film_launch_tiles_to_frame(t2, s);
+    if (e == hipSuccess) e = hipEventRecord(h->pipe_ev[1], s);
+    return e;
+  };
+  HIPCHK(h, hipMemcpyAsync(st, x0, frame_bytes, hipMemcpyHostToDevice, s));
+  tp.ntiles = nt; tp.src = st; tp.dst = P->arena + img0.off;
+  HIPCHK(h, film_launch_frame_to_tiles(tp, s));
+  HIPCHK(h, hipEventRecord(h->pipe_ev[0], s));
+  HIPCHK(h, hipStreamWaitEvent(h->stream2, h->pipe_ev[0], 0));   // (the side stream: behind whatever `s` held before this call, too)
+  for (size_t i : lp.head) HIPCHK(h, launch_op(batch_part(P->ops[i], 0, 2), P->arena, h->packed_dev, s));
+  HIPCHK(h, hipMemcpyAsync(st + nf, x1, frame_bytes, hipMemcpyHostToDevice, h->stream2));
+  tp.src = st + nf; tp.dst = P->arena + img0.off + (int64_t)nt * tp.TH * tp.TW * 3;
+  HIPCHK(h, film_launch_frame_to_tiles(tp, h->stream2));
+  HIPCHK(h, hipEventRecord(h->pipe_ev[0], h->stream2));
+  HIPCHK(h, hipStreamWaitEvent(s, h->pipe_ev[0], 0));
+  const hipError_t le = issue_lanes(h, P, s, false, &lp);
+  if (le != hipSuccess) { (void)hipStreamSynchronize(h->stream2); return fail(h, FILM_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(le)); }
+  h->last_plan = P;
+  const int64_t tile_floats = (int64_t)tp.TH * tp.TW * 3;
+  if (lp.tail) {
+    TileMapParams t2 = tp;
+    t2.tile0 = nt / 2; t2.ntiles = nt - nt / 2; t2.src = P->arena + ob.off + (int64_t)(nt / 2) * tile_floats; t2.dst = st + 2 * nf;
+    HIPCHK(h, film_launch_tiles_to_frame(t2, s));
+    const size_t half = frame_bytes / 2;   // (one frame, an even number of block rows: the upper half of the rows)
+    HIPCHK(h, hipStreamWaitEvent(h->stream2, h->pipe_ev[1], 0));
+    HIPCHK(h, hipMemcpyAsync(out, st + 2 * nf, half, hipMemcpyDeviceToHost, h->stream2));
+    HIPCHK(h, hipMemcpyAsync((char*)out + half, (const char*)(st + 2 * nf) + half, frame_bytes - half, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(h->stream2));
+  } else {
+    tp.tile0 = 0; tp.ntiles = nt; tp.src = P->arena + ob.off; tp.dst = st + 2 * nf;
+    HIPCHK(h, film_launch_tiles_to_frame(tp, s));
+    HIPCHK(h, hipMemcpyAsync(out, st + 2 * nf, frame_bytes, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(h, hipStreamSynchronize(s));
   return FILM_OK;
 }
 

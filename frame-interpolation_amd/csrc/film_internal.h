@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <memory>
 #include <sstream>
@@ -196,6 +197,9 @@ struct film_handle {
   int opt_graph = 2;
   int opt_profile = 0, opt_autotune = 1;
   int opt_max_batch = 0;  // 0: only the 4 GiB-per-buffer limit
+  int opt_host_overlap = 1;   // film_interpolate(FILM_MEM_HOST): 1 = the second frame's upload behind the first frame's first layers, the first half of the
+                              // result downloaded behind the second half's last layer (film_engine.cpp, "host pipeline"); 0 = copies, then work, then copy
+  hipEvent_t pipe_ev[2] = {nullptr, nullptr};   // its two events (second frame in place / first half stitched), lazily created
   int opt_splitk = 1;     // 1: split-K (ksplit partial sums + ordered reduction) for the deep layers of levels with <= 1024 pixels
   int opt_fuse = 31;       // 1: flow_up fused into the flow-estimator warps, v = res + up into the flow heads (same arithmetic, 12 launches fewer)
   int opt_planar = 1;     // 1: aligned-pyramid levels as three planes (feat0 | feat1 | misc16), each written contiguously by its warp

@@ -315,16 +315,21 @@ class FilmEngine:
                                            ctypes.c_void_p(stream) if stream else None))
 
     def interpolate_frames(self, x0: np.ndarray, x1: np.ndarray, align: Optional[int] = None,
-                           block_shape=None) -> np.ndarray:
+                           block_shape=None, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Interpolator.__call__ semantics in one C-ABI call (film_interpolate): pad to `align`, optional
-        block_shape = (bh, bw) tiling with per-patch padding, crop, stitch - all on the device."""
+        block_shape = (bh, bw) tiling with per-patch padding, crop, stitch - all on the device.
+        `out`: an optional C-contiguous float32 array of x0's shape to receive the frame (a caller that reuses one - pinned, see
+        torch_io.pinned_frame - saves the page faults of a fresh 25 MB array per call); default: a new array, like the reference."""
         x0 = np.ascontiguousarray(x0, dtype=np.float32)
         x1 = np.ascontiguousarray(x1, dtype=np.float32)
         if x0.ndim != 4 or x0.shape[3] != 3 or x0.shape != x1.shape:
             raise ValueError(f'expected two [B,H,W,3] arrays of equal shape, got {x0.shape} and {x1.shape}')
         b, h, w, _ = x0.shape
         bh, bw = (int(block_shape[0]), int(block_shape[1])) if block_shape else (1, 1)
-        out = np.empty_like(x0)
+        if out is None:
+            out = np.empty_like(x0)
+        elif out.dtype != np.float32 or out.shape != x0.shape or not out.flags['C_CONTIGUOUS'] or not out.flags['WRITEABLE']:
+            raise ValueError(f'out must be a writable C-contiguous float32 array of shape {x0.shape}')
         self._check(self._lib.film_interpolate(self._h, x0.ctypes.data, x1.ctypes.data, b, h, w, int(align or 0),
                                                bh, bw, out.ctypes.data, FILM_MEM_HOST, None))
         self.save_tune_cache()

@@ -14,6 +14,12 @@ import torch
 from .engine import FilmEngine
 
 
+def pinned_frame(shape) -> 'np.ndarray':
+    """A float32 numpy array in page-locked host memory (the tensor that owns it rides along as `.base`): frames handed to
+    Interpolator.__call__ / FilmEngine.interpolate_frames in such arrays move at the PCIe rate without the runtime pinning pageable pages per call."""
+    return torch.empty(tuple(int(v) for v in shape), dtype=torch.float32, pin_memory=True).numpy()
+
+
 def pad_to_align(x: torch.Tensor, align: int) -> Tuple[torch.Tensor, Tuple[int, int, int, int]]:
     """[B,H,W,C] -> zero padded to multiples of align, offset pad//2 (eval/interpolator.py:30-63)."""
     b, h, w, c = x.shape

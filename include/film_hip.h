@@ -215,7 +215,10 @@ int film_interpolate(film_t* h, const float* x0, const float* x1, int B, int H, 
  *   "fold4_shape" n  the same for conv_fold4_kernel (Fold4Tile).
  *   "max_batch" n  process at most n frame pairs / tiles per model invocation (0 = only the built-in limits: 64 GiB of
  *                  workspace, 4 GiB per buffer read through a whole-buffer 32-bit offset); frame pairs are independent,
- *                  results do not change */
+ *                  results do not change
+ *   "host_overlap" 0/1  1 (default): film_interpolate with FILM_MEM_HOST pipelines its copies with the work - the second frame is uploaded
+ *                  while the first layers run on the first frame's tiles, the upper half of the result is downloaded while the last layer
+ *                  computes the lower half (one frame, an even number of block rows); 0: upload, work, download.  Same bits. */
 int film_set_option(film_t* h, const char* key, int64_t value);
 
 /* Autotune choices across processes.  film_export_tune writes text (buf / capacity / needed as film_plan_json): a header

@@ -384,3 +384,32 @@ def test_two_pairs_in_one_invocation_cross_4gib_through_the_batch_index(publishe
     assert np.array_equal(both, one), float(np.abs(both - one).max())
     # and not trivially equal: the two pairs differ
     assert not np.array_equal(both[0], both[1])
+
+
+@pytest.mark.parametrize('shape,block', [((1, 1080, 1920, 3), (2, 2)), ((1, 720, 1280, 3), (2, 2)), ((1, 256, 256, 3), None), ((2, 360, 640, 3), (2, 1)),
+                                         ((1, 1080, 1920, 3), (4, 4)), ((1, 540, 960, 3), (1, 2))])
+def test_host_buffer_pipeline_is_bit_identical(published, shape, block):
+    """film_interpolate with host buffers (the reference's numpy -> numpy call, eval/interpolator.py:152-209) pipelines its copies with the work
+    (option "host_overlap": the first layers run per input frame, the last layer per tile half - batch parts of a convolution).  Same bits as the
+    unpipelined call, with one frame and several, even and odd block rows (the tail split needs one frame and an even number of block rows),
+    pageable arrays, a caller-owned `out`, and pinned arrays."""
+    import inputs
+    from film_hip.torch_io import pinned_frame
+    opt, wts, eng = published
+    b, h, w, _ = shape
+    x0, x1 = inputs.frame_pair(b, h, w, 77 + h)
+    eng.set_option('host_overlap', 0)
+    try:
+        plain = eng.interpolate_frames(x0, x1, align=64, block_shape=block)
+    finally:
+        eng.set_option('host_overlap', 1)
+    piped = eng.interpolate_frames(x0, x1, align=64, block_shape=block)
+    assert np.array_equal(piped, plain), float(np.abs(piped - plain).max())
+    mine = np.full_like(x0, -1.0)
+    got = eng.interpolate_frames(x0, x1, align=64, block_shape=block, out=mine)
+    assert got is mine and np.array_equal(mine, plain)
+    p0, p1, po = pinned_frame(shape), pinned_frame(shape), pinned_frame(shape)
+    p0[:] = x0; p1[:] = x1
+    assert np.array_equal(eng.interpolate_frames(p0, p1, align=64, block_shape=block, out=po), plain)
+    with pytest.raises(ValueError):
+        eng.interpolate_frames(x0, x1, align=64, block_shape=block, out=np.empty((1, 2, 2, 3), np.float32))
