@@ -49,6 +49,10 @@
 enum { W2D_F_SQ = 128,         // the 32 units of a tile as 8 unit rows x 4 units = 16 x 16 pixels instead of 4 x 8 = 8 rows x 32 pixels: levels whose width is
                                // a multiple of 16 but not of 32 (144x240: 7.5 tiles per row, 6.25 % of the MFMA columns masked) tile exactly.  18 halo rows of 18
                                // pixels (row pitch 82 slots) fill the same 24 requests per stage.  Same sums, same bits.
+       W2D_F_EPI1 = 16,        // tools only (round 6, rejected): epilogue on FOUR exchange buffers - every wave writes its four x positions, ONE barrier, then the
+                               // four rounds of reads / stores (instead of a barrier per round on two buffers); 64 KB (32 channels) / 128 KB (64) of LDS, not with
+                               // the fused 1x1.  Stand-alone -2..-12 % for the 8 x 32 tiles, +5..7 % for the 32-channel 16 x 16 ones; in the engine nothing
+                               // (same-box A/B: conv_wino2d_kernel 29.18 vs 29.16-29.6 ms per forward, the K > 528 layers slower): profiles/r06_w2d_epilogue_one_barrier.log
        W2D_F_CHAIN = 64,       // a workgroup walks ConvParams::chain consecutive pixel tiles (same output channels): the DMA cursor and the weight
                                // requests run on into the next tile while this one finishes, the epilogue's exchange buffers lie BEHIND the stages
                                // (see "chained tiles" below).  Same sums, same bits.
@@ -542,7 +546,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     }
     bf4* const xb = reinterpret_cast<bf4*>(smem) + (CHAIN ? NS * STAGE4 : 0);   // [buffer 2][ng][mu][unit 32][piece 8] float4
     constexpr int XB4 = NG * 4 * 256;
-    static_assert(CHAIN || 2 * XB4 <= NS * STAGE4, "exchange buffers");
+    constexpr bool E1 = (FLAGS & W2D_F_EPI1) != 0 && !CHAIN;
+    static_assert(CHAIN || E1 || 2 * XB4 <= NS * STAGE4, "exchange buffers");
     const int widx = (ng * 4 + mu) * 256 + l31 * 8;   // + ((2 g + half) ^ (unit & 7))
     const int rng = t >> 8, run = (t >> 3) & 31, rcg = t & 7;   // reader: channel tile, unit, 4-channel group
     const int ridx = rng * 1024 + run * 8 + (rcg ^ (run & 7));  // + mu * 256
@@ -570,16 +575,26 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     float* const pww = pwt + TH * PXW * PWS;   // [64][4]
     if (p.pw_out != nullptr && t < 256) pww[t] = (t & 3) < p.pw_cout ? p.pw_w[(t >> 2) * p.pw_cout + (t & 3)] : 0.f;   // (published by the rounds' barriers)
     bf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
-  #pragma unroll
-    for (int jx = 0; jx < 4; ++jx) {
-      bf4* const xw = xb + (jx & 1) * XB4;
+    auto write_round = [&](int jx, bf4* xw) {
   #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf4 v;
         v[0] = o[jx][4 * g]; v[1] = o[jx][4 * g + 1]; v[2] = o[jx][4 * g + 2]; v[3] = o[jx][4 * g + 3];
         xw[widx + ((2 * g + half) ^ (l31 & 7))] = v;
       }
+    };
+    if constexpr (E1) {
+  #pragma unroll
+      for (int jx = 0; jx < 4; ++jx) write_round(jx, xb + jx * XB4);
       __syncthreads();
+    }
+  #pragma unroll
+    for (int jx = 0; jx < 4; ++jx) {
+      bf4* const xw = xb + (E1 ? jx : (jx & 1)) * XB4;
+      if constexpr (!E1) {
+        write_round(jx, xw);
+        __syncthreads();
+      }
       const bf4 m0 = xw[ridx], m1 = xw[ridx + 256], m2 = xw[ridx + 512], m3 = xw[ridx + 768];
       // Packed, and without compare / select: max(v, slope v) is leaky_relu(0.2) for slope = 0.2 and v itself for slope = 1 (same bits as the
       // v > 0 ? v : 0.2 v form, NaN and -0 included); 24 instead of 46 vector instructions per round (they are taken from the matrix pipe of
@@ -690,8 +705,11 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   constexpr bool CHAIN = (FLAGS & W2D_F_CHAIN) != 0;
   // NS stages of 24 KB; the exchange buffers (2 x BN / 32 x 16 KB) fit inside them - or, chained, lie behind them (80 KB for the 32-channel
   // tile on two stages: two workgroups per CU; 136 KB for the 64-channel one); the fused 1x1 adds its [256][68] tile and its weights
+  constexpr bool E1 = (FLAGS & W2D_F_EPI1) != 0 && !CHAIN;
+  if (E1 && p.pw_out) return hipErrorInvalidValue;   // (the fused 1x1's pixel tile lies behind TWO exchange buffers)
   const size_t lds = CHAIN ? (size_t)NS * 24 * 1024 + (size_t)2 * (BN / 32) * 16 * 1024
-                           : p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024 : (size_t)NS * 24 * 1024;
+                           : p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024
+                           : E1 ? std::max((size_t)NS * 24 * 1024, (size_t)4 * (BN / 32) * 16 * 1024) : (size_t)NS * 24 * 1024;
   constexpr int NT = 4 * (BN / 32) * 64;
   if (p.ksize != 3 || p.Ctot % 16 || p.Cout % BN) return hipErrorInvalidValue;
   if (CHAIN && (p.ksplit > 1 || p.pw_out || p.chain < 1)) return hipErrorInvalidValue;

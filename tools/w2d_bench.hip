@@ -158,6 +158,8 @@ static Variant variants[] = {
     W2C("32 ns2 ch1", 32, 2, 1), W2C("32 ns2 ch2", 32, 2, 2), W2C("32 ns2 ch4", 32, 2, 4), W2C("32 ns2 ch8", 32, 2, 8),
     W2C("64 ns3 ch1", 64, 3, 1), W2C("64 ns3 ch2", 64, 3, 2), W2C("64 ns3 ch4", 64, 3, 4), W2C("64 ns3 ch8", 64, 3, 8),
     {"w2d 32 ns2 plain", 32, 1, conv_wino2d_launch<32, 4, 2>},
+    {"w2d 32 ns2 e1", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_EPI1, 2>}, {"w2d 32 ns2 sq e1", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ | W2D_F_EPI1, 2>},
+    {"w2d 64 ns3 e1", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_EPI1, 3>}, {"w2d 64 ns3 sq e1", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_SQ | W2D_F_EPI1, 3>},
     {"w2d 32 ns2 sq", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ, 2>}, {"w2d 32 ns3 sq", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ, 3>}, {"w2d 64 ns3 sq", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_SQ, 3>},
     {"w2d 32 ns2 lds+24", 32, 1, w2d_ns2_lds<24>}, {"w2d 32 ns2 lds+30", 32, 1, w2d_ns2_lds<30>}, {"w2d 32 ns2 lds+32", 32, 1, w2d_ns2_lds<32>},
     W2N("64 time", 64, 4 | W2D_DBG_TIME), W2N("32 time", 32, 4 | W2D_DBG_TIME),
