@@ -31,7 +31,7 @@ if ! skip configs; then
 fi
 if ! skip tests; then
   timeout 60 python __graft_entry__.py smoke > $O/${TAG}_smoke.log 2>&1; echo "smoke rc=$?"; grep -i smoke $O/${TAG}_smoke.log | tail -2
-  timeout 900 python -m pytest tests -m gpu -q -s > $O/${TAG}_gpu_tests_full.log 2>&1
+  timeout 900 python -m pytest tests -m gpu -q -s -rs > $O/${TAG}_gpu_tests_full.log 2>&1
   echo "tests rc=$?"; grep -v "^\[W\|amdgpu.ids" $O/${TAG}_gpu_tests_full.log > $O/${TAG}_gpu_tests.log; rm -f $O/${TAG}_gpu_tests_full.log; grep -i "passed\|failed" $O/${TAG}_gpu_tests.log | tail -3; lap tests
 fi
 du -sh $O
