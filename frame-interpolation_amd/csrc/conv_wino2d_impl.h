@@ -80,6 +80,25 @@ constexpr bool w2d_quotient_exact(unsigned d, unsigned n) {   // (x * magic) >> 
   return n < (1u << 12) && w2d_magic20(d) < (1u << 20);
 }
 
+// DMA slot -> (halo row r, halo pixel px, 16-byte piece c) of the stage layout above, as a compile-time table: r << 24 | px << 8 | c << 4, ~0 for
+// the padding slots of a row / behind the last halo row.  The kernel reads a lane's NREQ / NW entries with one vector load each at kernel
+// entry (6 KB per arrangement, cache resident) instead of decomposing the slot number with three multiply-shift quotients per request -
+// 115 of the ~150 vector instructions in front of the first DMA request (each one waits for an issue slot the co-resident workgroup's K
+// loop leaves free: round 6, "table prologue" below).
+template <bool SQ> struct W2dSlotTable { unsigned v[24 * 64]; };
+template <bool SQ> constexpr W2dSlotTable<SQ> w2d_make_slot_table() {
+  constexpr int QW = SQ ? 4 : 8, TH = SQ ? 16 : 8, HR = TH + 2, PW = 4 * QW + 2;
+  constexpr int CO4 = (PW + 3) / 4, MO4 = 4 * CO4, RP4 = 4 * MO4 + (SQ ? 2 : 4);
+  W2dSlotTable<SQ> t{};
+  for (int sl = 0; sl < 24 * 64; ++sl) {
+    const int r = sl / RP4, rem = sl % RP4, m = rem / MO4, rr = rem % MO4, c = rr / CO4, k = rr % CO4, px = 4 * k + m;
+    const bool ok = r < HR && rem < 4 * MO4 && px < PW;
+    t.v[sl] = ok ? ((unsigned)r << 24 | (unsigned)px << 8 | (unsigned)c << 4) : 0xFFFFFFFFu;
+  }
+  return t;
+}
+template <bool SQ> __device__ const W2dSlotTable<SQ> w2d_slot_table = w2d_make_slot_table<SQ>();
+
 template <int BN, int FLAGS, int NS_ = 3>
 __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_wino2d_kernel(ConvParams p) {
   constexpr bool SQ = (FLAGS & W2D_F_SQ) != 0;
@@ -116,17 +135,40 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // ~19 cycles each - the co-resident workgroup's K loop owns the issue slots - i.e. 9 000-11 000 cycles of a 45 000-cycle workgroup
   // (profiles/r06_w2d_valu_diet.log).  So: quotients by host-made reciprocals (ConvParams::mg_*; exact for x d < 2^32, which the
   // launcher checks), unsigned slot arithmetic without branches, and no accumulator clearing (the first chunk's MFMAs take C = 0).
-  auto udiv = [](unsigned x, unsigned d, unsigned magic) -> unsigned { return magic ? __umulhi(x, magic) : x / d; };
+  // Table prologue (round 6, second pass).  (a) Every kernel argument the code in front of the first DMA request reads is loaded HERE, in one
+  // batch behind one s_waitcnt: hipcc placed each s_load at its first use, behind the branches of the fallback divisions - seven dependent
+  // round trips to the scalar cache (~250 cycles each with nothing else to issue) before the first request.  The reciprocals are now
+  // mandatory (0 only for a divisor of 1; the launcher refuses what it cannot make exact), so no division code and no branches are left.
+  // (b) A lane's slot entries come from w2d_slot_table (above), requested first of all.
+  int aH = p.H, aW = p.W, aNB = p.NB, aCtot = p.Ctot, aKsplit = p.ksplit, aNseg = p.nseg, aChain = p.chain;
+  unsigned a_tpi = p.mg_tpi, a_ntx = p.mg_ntx, a_nby = p.mg_nby;
+  int aGx = (int)gridDim.x, aGy = (int)gridDim.y;
+  const float* aS0ptr = p.seg[0].ptr;
+  int aS0stride = p.seg[0].stride, aS0C = p.seg[0].C, aS0boff = p.seg[0].boff, aS0bmod = p.seg[0].bmod;
+  const float* aWptr = p.w;
+  unsigned rtab[(24 / (4 * (BN / 32)))];
+  if constexpr (!CHAIN) {
+#pragma unroll
+    for (int n = 0; n < 24 / NW; ++n) rtab[n] = w2d_slot_table<SQ>.v[t + 64 * NW * n];
+  }
+  {
+    unsigned long long q0 = (unsigned long long)(uintptr_t)aS0ptr, q1 = (unsigned long long)(uintptr_t)aWptr;
+    asm volatile("" : "+s"(aH), "+s"(aW), "+s"(aNB), "+s"(aCtot), "+s"(aKsplit), "+s"(aNseg), "+s"(aChain), "+s"(a_tpi), "+s"(a_ntx), "+s"(a_nby),
+                      "+s"(aGx), "+s"(aGy), "+s"(q0), "+s"(q1), "+s"(aS0stride), "+s"(aS0C), "+s"(aS0boff), "+s"(aS0bmod));
+    aS0ptr = reinterpret_cast<const float*>((uintptr_t)q0);
+    aWptr = reinterpret_cast<const float*>((uintptr_t)q1);
+  }
+  auto udiv = [](unsigned x, unsigned magic) -> unsigned { return magic ? __umulhi(x, magic) : x; };   // magic = 0: divisor 1
   int bx = blockIdx.x, by = blockIdx.y;
   if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
-    const int nbx = gridDim.x, nby = gridDim.y;
+    const int nbx = aGx, nby = aGy;
     const int nwg = nbx * nby;
     const int lin = by * nbx + bx;
     const int xcd = lin & 7, idx = lin >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     const int nl = base + idx;
-    bx = (int)udiv((unsigned)nl, (unsigned)nby, p.mg_nby);
+    bx = (int)udiv((unsigned)nl, a_nby);
     by = nl - bx * nby;
   }
   // Chained tiles (W2D_F_CHAIN): this workgroup owns the pixel tiles [g0, g0 + nt) of the launch, nt <= p.chain, one after the other.
@@ -135,13 +177,13 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // are requested by the ordinary in-loop DMA / weight stream of the current tile (the cursor simply runs on: no burst in front of
   // the epilogue, which is what sank round 4's attempt), land during its last chunks and its epilogue, and the next K loop starts
   // right behind the epilogue.  The exchange buffers then cannot overlay the stages: they lie behind them.
-  const int ntx = (p.W + PXW - 1) / PXW, nty = (p.H + TH - 1) / TH;
+  const int ntx = (aW + PXW - 1) / PXW, nty = (aH + TH - 1) / TH;
   const int tpi = ntx * nty;                                    // tiles per image
-  const int chain = CHAIN ? (p.chain > 1 ? p.chain : 1) : 1;
+  const int chain = CHAIN ? (aChain > 1 ? aChain : 1) : 1;
   const int g0 = bx * chain;
-  const int nt = CHAIN ? min(chain, p.NB * tpi - g0) : 1;       // tiles of this workgroup
-  int img = (int)udiv((unsigned)g0, (unsigned)tpi, p.mg_tpi);
-  const int trow0 = (int)udiv((unsigned)(g0 - img * tpi), (unsigned)ntx, p.mg_ntx);
+  const int nt = CHAIN ? min(chain, aNB * tpi - g0) : 1;       // tiles of this workgroup
+  int img = (int)udiv((unsigned)g0, a_tpi);
+  const int trow0 = (int)udiv((unsigned)(g0 - img * tpi), a_ntx);
   int y0 = trow0 * TH, x0 = (g0 - img * tpi - trow0 * ntx) * PXW;   // the tile the MFMAs / the epilogue are at
   int c_t = 0, c_img = img, c_y0 = y0, c_x0 = x0;               // the tile the DMA cursor is at
   const int n0 = by * BN;
@@ -154,50 +196,58 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // ---- DMA side: request n of this wave fills slots 64 * (wv + NW n) ... + 63 of a stage; lane -> (halo row, pixel, piece) -----
   unsigned rvoff[IPW];
   int rsg = 0, rc0 = 0, rsegC = 0;
-  conv_rsrc_t rrsrc = conv_make_rsrc(uniform_ptr(p.seg[0].ptr));
+  conv_rsrc_t rrsrc = conv_make_rsrc(uniform_ptr(aS0ptr));
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
   // Which (halo row, pixel, 16-byte piece) a lane's slot is, and whether that pixel lies in the image, does not depend on the input
-  // segment: (pixel offset from the first halo row) << 2 | piece, or ~0 for padding / outside ('same' padding = zeros), once per
-  // workgroup - the three divisions per request used to be redone for every segment set-up, inlined at four places (a third of the
-  // 1 190 instructions in front of the first MFMA; two waves per SIMD issue those at ~8 cycles each: the prologue is issue bound).
+  // segment: (pixel offset from the halo patch's first pixel) << 2 | piece, or ~0 for padding / outside ('same' padding = zeros), once per
+  // workgroup.  The slot's (row, pixel, piece) is a table entry (w2d_slot_table); a tile whose halo lies inside the image (a scalar test)
+  // needs no bounds tests at all; a segment set-up then forms the byte offsets with two 24-bit multiply-adds per request.
   // Chained tiles: the tile-INDEPENDENT part of it (halo row | pixel << 8 | piece << 16 | slot in use << 31) is kept instead, and a tile /
   // segment set-up forms the offsets from it and the cursor's tile - behind an opaque copy, or hipcc hoists the unpacked fields out
   // of the tile loop (18 registers, spilled, reloaded with s_waitcnt vmcnt(0) in the middle of the K loop).
   unsigned rpk[IPW];
   auto quot20 = [](unsigned x, unsigned magic) -> unsigned { unsigned q; asm("v_mul_u32_u24 %0, %1, %2\n\tv_lshrrev_b32 %0, 20, %0" : "=v"(q) : "v"(x), "s"(magic)); return q; };
   auto mad24 = [](unsigned a, int b, unsigned c) -> unsigned { unsigned q; asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(q) : "v"(a), "s"(b), "v"(c)); return q; };
+  auto madu24 = [](unsigned a, unsigned b, unsigned c) -> unsigned { unsigned q; asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(q) : "v"(a), "s"(b), "v"(c)); return q; };
   auto set_rpk = [&]() {   // for the cursor's tile (chained: tile independent, called once)
-    const int H = p.H, W = p.W;
+    const int H = aH, W = aW;
+    if constexpr (CHAIN) {
 #pragma unroll
-    for (int n = 0; n < IPW; ++n) {
-      // slot -> (halo row r, pixel 4 k + m, piece c): multiply-shift quotients, exact on [0, NREQ * 64) (static_asserts below)
-      // (24-bit forms spelled out: hipcc does not know that a slot number is small and emits the quarter-rate v_mul_lo_u32 / v_mad_u64_u32 -
-      // every vector instruction of a prologue is taken from the co-resident workgroup's matrix pipe)
-      const unsigned sl = 64u * (unsigned)(wv + NW * n) + (unsigned)lane;
-      const unsigned r = quot20(sl, w2d_magic20(RP4)), rem = mad24(r, -RP4, sl);
-      const unsigned m = quot20(rem, w2d_magic20(MO4)), rr = mad24(m, -MO4, rem);
-      const unsigned c = quot20(rr, w2d_magic20(CO4)), k = mad24(c, -CO4, rr);
-      const unsigned px = 4u * k + m;
-      const unsigned slot_ok = (unsigned)(r < (unsigned)HR) & (unsigned)(rem < 4u * MO4) & (unsigned)(px < (unsigned)PW);
-      if constexpr (CHAIN) {
+      for (int n = 0; n < IPW; ++n) {
+        // slot -> (halo row r, pixel 4 k + m, piece c): multiply-shift quotients, exact on [0, NREQ * 64) (static_asserts above)
+        const unsigned sl = 64u * (unsigned)(wv + NW * n) + (unsigned)lane;
+        const unsigned r = quot20(sl, w2d_magic20(RP4)), rem = mad24(r, -RP4, sl);
+        const unsigned m = quot20(rem, w2d_magic20(MO4)), rr = mad24(m, -MO4, rem);
+        const unsigned c = quot20(rr, w2d_magic20(CO4)), k = mad24(c, -CO4, rr);
+        const unsigned px = 4u * k + m;
+        const unsigned slot_ok = (unsigned)(r < (unsigned)HR) & (unsigned)(rem < 4u * MO4) & (unsigned)(px < (unsigned)PW);
         rpk[n] = r | px << 8 | c << 16 | (slot_ok ? 0x80000000u : 0u);
-      } else {
-        const unsigned y = (unsigned)(c_y0 - 1) + r, x = (unsigned)(c_x0 - 1) + px;   // (wraps below 0: fails the unsigned bound)
-        const unsigned ok = slot_ok & (unsigned)(y < (unsigned)H) & (unsigned)(x < (unsigned)W);   // else padding / outside the image
-        rpk[n] = ok ? mad24(r, W, x) << 2 | c : OOB;   // (W < 2^20: the launcher checks)
+      }
+    } else {
+      // rpk = the table entry, or ~0 where the slot's pixel lies outside the image: nothing to do for a tile whose halo lies inside (a scalar
+      // test; the buffer resource of a segment starts at the halo patch's first pixel (c_y0 - 1, c_x0 - 1): offsets count from there)
+      const bool inside = c_y0 >= 1 && c_y0 + TH + 1 <= H && c_x0 >= 1 && c_x0 + PXW + 1 <= W;
+#pragma unroll
+      for (int n = 0; n < IPW; ++n) {
+        const unsigned tv = rtab[n];
+        unsigned v = tv;
+        if (!inside) {
+          const unsigned y = (unsigned)(c_y0 - 1) + (tv >> 24), x = (unsigned)(c_x0 - 1) + ((tv >> 8) & 255u);   // (wraps below 0: fails the unsigned bound;
+          v = ((y < (unsigned)H) & (x < (unsigned)W)) ? tv : OOB;                                                //  a padding slot: row 255)
+        }
+        rpk[n] = v;
       }
     }
   };
   set_rpk();
-  auto raw_setup_seg = [&]() {
-    const ConvSeg& s = p.seg[rsg];
-    rsegC = __builtin_amdgcn_readfirstlane(s.C);
-    int be = c_img + s.boff;
-    if (s.bmod && be >= s.bmod) be -= s.bmod;
+  auto raw_setup_seg_of = [&](const float* sptr, int sstride, int sC, int sboff, int sbmod) {
+    rsegC = __builtin_amdgcn_readfirstlane(sC);
+    int be = c_img + sboff;
+    if (sbmod && be >= sbmod) be -= sbmod;
     // (the finished pointer through readfirstlane: should hipcc ever reload `p` with vector loads - it does behind an atomic - a buffer
     // resource in VGPRs cannot feed the DMA statement - nor a buffer load without a waterfall loop)
-    rrsrc = conv_make_rsrc(uniform_ptr(s.ptr + ((long long)be * p.H + (c_y0 - 1)) * p.W * s.stride));
-    const unsigned st4 = (unsigned)s.stride * 4u;
+    rrsrc = conv_make_rsrc(uniform_ptr(sptr + (((long long)be * aH + (c_y0 - 1)) * aW + (CHAIN ? 0 : c_x0 - 1)) * sstride));
+    const unsigned st4 = (unsigned)sstride * 4u;
     if constexpr (CHAIN) {
 #pragma unroll
       for (int n = 0; n < IPW; ++n) {
@@ -205,13 +255,24 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
         asm volatile("" : "+v"(ri));
         const int r = (int)(ri & 255u), px = (int)((ri >> 8) & 255u);
         const int y = c_y0 - 1 + r, x = c_x0 - 1 + px;
-        const bool ok = (int)ri < 0 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-        rvoff[n] = ok ? (unsigned)(r * p.W + x) * st4 + ((ri >> 16) & 3u) * 16u : OOB;
+        const bool ok = (int)ri < 0 && (unsigned)y < (unsigned)aH && (unsigned)x < (unsigned)aW;
+        rvoff[n] = ok ? (unsigned)(r * aW + x) * st4 + ((ri >> 16) & 3u) * 16u : OOB;
       }
     } else {
+      const unsigned wst4 = (unsigned)aW * st4;   // (a halo row's bytes < 2^24: the launcher)
 #pragma unroll
-      for (int n = 0; n < IPW; ++n) rvoff[n] = rpk[n] == OOB ? OOB : __umul24(rpk[n] >> 2, st4) + (rpk[n] & 3u) * 16u;   // (pixel index, pixel pitch < 2^24: the launcher)
+      for (int n = 0; n < IPW; ++n) {
+        const unsigned tv = rpk[n];
+        unsigned off, tmp;   // (r W + px) pitch + 16 c; one statement: one temporary (this runs inside the K loop too, at the register limit)
+        asm("v_and_b32 %0, 48, %2\n\tv_bfe_u32 %1, %2, 8, 8\n\tv_mad_u32_u24 %0, %1, %3, %0\n\tv_lshrrev_b32 %1, 24, %2\n\tv_mad_u32_u24 %0, %1, %4, %0"
+            : "=&v"(off), "=&v"(tmp) : "v"(tv), "s"(st4), "s"(wst4));
+        rvoff[n] = tv == OOB ? OOB : off;
+      }
     }
+  };
+  auto raw_setup_seg = [&]() {
+    const ConvSeg& s = p.seg[rsg];
+    raw_setup_seg_of(s.ptr, s.stride, s.C, s.boff, s.bmod);
   };
   auto dma_piece = [&](int n, int stage) {   // request n of this wave's share of the cursor's super-chunk -> stage
     const unsigned so = (unsigned)rc0 * 4u;
@@ -222,7 +283,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   auto dma_advance = [&]() {   // the cursor moves to the next super-chunk (16 channels), into the next input segment behind the last one
     rc0 += 16;
     if (rc0 >= rsegC) {
-      if (rsg + 1 < p.nseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
+      if (rsg + 1 < aNseg) { rc0 = 0; ++rsg; raw_setup_seg(); }
       else if constexpr (CHAIN) {   // ... and into the next tile of the chain behind the last segment (a uniform branch, once per tile)
         if (c_t + 1 < nt) {
           ++c_t;
@@ -241,8 +302,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // activation.  The planner uses it for the K >= 768 layers of levels with <= 4096 pixels, whose workgroups do not fill the chip (36x60:
   // 640 workgroups on 512 slots); on the 72x120 level (2304 workgroups = 4.5 rounds) two K ranges gained 2-4 % stand-alone and nothing in
   // the forward (profiles/r05_w2d_splitk.log): not used there.
-  const int ksp = p.ksplit > 1 ? p.ksplit : 1;
-  const int nsc_all = p.Ctot >> 4;
+  const int ksp = aKsplit > 1 ? aKsplit : 1;
+  const int nsc_all = aCtot >> 4;
   int sc0 = 0, sc1 = nsc_all;
   if (ksp > 1) {   // (a uniform branch, 32-bit quotients: 460 instead of 740 instructions between kernel entry and the first DMA request of
                    // an unsplit launch - round 4's kernel had 380.  Same-box A/B on the K <= 64 ... 528 layer shapes: no measurable
@@ -250,7 +311,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     sc0 = (int)((unsigned)nsc_all * blockIdx.z / (unsigned)ksp);            // nsc_all * ksplit < 2^16 * 2^4
     sc1 = (int)((unsigned)nsc_all * (blockIdx.z + 1u) / (unsigned)ksp);
     int c = sc0 * 16;   // the DMA cursor starts at this split's first super-chunk: walk the concat segments
-    while (rsg + 1 < p.nseg && c >= p.seg[rsg].C) { c -= p.seg[rsg].C; ++rsg; }
+    while (rsg + 1 < aNseg && c >= p.seg[rsg].C) { c -= p.seg[rsg].C; ++rsg; }
     rc0 = c;
   }
   auto raw_issue = [&](int stage) {
@@ -260,8 +321,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   };
 
   // ---- weights: [Cout / 32][chunk][mu][nu][K half][32][4] floats; this wave reads slab (ct, kc, mu): 6 x 1 KB -----------------
-  const int nkc = p.Ctot / 8, nsc = sc1 - sc0, kc0 = 2 * sc0, kc1 = 2 * sc1;
-  const conv_rsrc_t brsrc = conv_make_rsrc(uniform_ptr(p.w));
+  const int nkc = aCtot / 8, nsc = sc1 - sc0, kc0 = 2 * sc0, kc1 = 2 * sc1;
+  const conv_rsrc_t brsrc = conv_make_rsrc(uniform_ptr(aWptr));
   const unsigned bvoff = (unsigned)((half * 32 + l31) * 16);
   const int ct = n0 / 32 + ng;
   // (past the end of the K range: a chained workgroup wraps to the first chunks - the next tile's; otherwise the last chunk again, unused)
@@ -369,7 +430,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // stage 0 has landed.  Issued up front (rounds 3-4a) they queued in front of the slower waves' stage-0 requests: the barrier came
   // 5 800 cycles after wave 0's own share had landed, now 2 900 (profiles/r04_w2d_prologue_order.log: -2 .. -10 % per layer, most on
   // the short-K layers; super-chunk 1 now lands during chunk 0's MFMAs instead of during the wait).
-  raw_setup_seg();
+  if (ksp > 1) raw_setup_seg();   // (a split's cursor may start in any segment)
+  else raw_setup_seg_of(aS0ptr, aS0stride, aS0C, aS0boff, aS0bmod);
   raw_issue(0);
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmA = __builtin_readcyclecounter();
 #pragma unroll
@@ -721,7 +783,7 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   if (p.W <= 0 || p.H <= 0 || p.W >= (1 << 20) || p.ostride >= (1 << 22) || p.pool_ostride >= (1 << 22) || p.Cout >= (1 << 22) ||
       (long long)8 * p.W * (p.ostride > p.Cout ? p.ostride : p.Cout) >= (1ll << 31)) return hipErrorInvalidValue;   // 24-bit multiplies of the DMA offsets: 10 halo rows x W pixels < 2^24
   for (int i = 0; i < p.nseg; ++i)
-    if (p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].stride <= 0 || p.seg[i].stride >= (1 << 22) || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
+    if ((long long)p.W * p.seg[i].stride * 4 >= (1ll << 24) || p.seg[i].C % 16 || p.seg[i].stride % 4 || p.seg[i].stride <= 0 || p.seg[i].stride >= (1 << 22) || p.seg[i].up || (reinterpret_cast<uintptr_t>(p.seg[i].ptr) & 15)) return hipErrorInvalidValue;
   auto kern = conv_wino2d_kernel<BN, FLAGS, NS>;
   static ConvLdsAttrFlags attr_flags;   // one per kernel instantiation (this launcher is a template)
   if (const hipError_t e = conv_allow_dynamic_lds(reinterpret_cast<const void*>(kern), attr_flags, 144 * 1024); e != hipSuccess) return e;
@@ -729,11 +791,17 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   const int ntx = SQ ? (p.W + 15) / 16 : (p.W + 31) / 32, nty = SQ ? (p.H + 15) / 16 : (p.H + 7) / 8;
   const int ntiles = p.NB * ntx * nty, chain = CHAIN ? p.chain : 1;
   dim3 grid((unsigned)((ntiles + chain - 1) / chain), p.Cout / BN, (unsigned)(p.ksplit > 1 ? p.ksplit : 1));
-  ConvParams q = p;   // + the reciprocals of the workgroup decomposition: ceil(2^32 / d), exact for x d < 2^32 (else 0 = divide)
-  auto magic = [](unsigned long long d, unsigned long long xmax) -> unsigned { return (d <= 1 || xmax * d >= (1ull << 32)) ? 0u : (unsigned)(((1ull << 32) + d - 1) / d); };
+  ConvParams q = p;   // + the reciprocals of the workgroup decomposition: ceil(2^32 / d), exact for x d < 2^32; 0 = the divisor is 1 (the kernel has no division code)
+  bool exact = true;
+  auto magic = [&exact](unsigned long long d, unsigned long long xmax) -> unsigned {
+    if (d <= 1) return 0u;
+    if (xmax * d >= (1ull << 32)) { exact = false; return 0u; }
+    return (unsigned)(((1ull << 32) + d - 1) / d);
+  };
   q.mg_nby = magic(grid.y, (unsigned long long)grid.x * grid.y);
   q.mg_tpi = magic((unsigned long long)ntx * nty, (unsigned long long)ntiles + chain);
   q.mg_ntx = magic(ntx, (unsigned long long)ntx * nty);
+  if (!exact) return hipErrorInvalidValue;   // (> 2^32 / tiles-per-image workgroups: no plan comes near)
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds + (size_t)conv_wino2d_debug_extra_lds(), s, q);
   return hipGetLastError();
 }

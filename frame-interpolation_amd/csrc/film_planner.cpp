@@ -205,7 +205,9 @@ struct Planner {
     // a multiple of 16 channels at 16-byte aligned pixels, a 16-byte aligned output slice (true of every such layer of the
     // published net; a property of the layer's buffers, so still a function of the layer only)
     bool w2d_layout = ctot % 16 == 0 && out.off % 4 == 0 && out.stride % 4 == 0;
-    for (int i = 0; i < op.nseg; ++i) w2d_layout = w2d_layout && segs[i].v.C % 16 == 0 && segs[i].v.off % 4 == 0 && segs[i].v.stride % 4 == 0;
+    // (round 6: ... and a halo row of a segment, W pixels x the pixel pitch, below 2^24 bytes - the DMA offsets are two 24-bit multiply-adds)
+    for (int i = 0; i < op.nseg; ++i)
+      w2d_layout = w2d_layout && segs[i].v.C % 16 == 0 && segs[i].v.off % 4 == 0 && segs[i].v.stride % 4 == 0 && (int64_t)W * segs[i].v.stride * 4 < (1ll << 24);
     // Round 6: ... and on SMALLER levels (>= opt_w2d_small_px = 256 pixels) whose shape fills at least 65 % of its 8-row x 32-pixel tiles:
     // 18x30 (a 1080p tile's level 5: 70 %), 32x32 (a 256x256 pair: 100 %), 16x28 (a 448x256 pair: 87 %) yes, 16x16 (50 %) and 9x15 (26 %)
     // no - its split-K (round 5) fills the chip where the tile count does not.  A/B of the threshold over three configs:
