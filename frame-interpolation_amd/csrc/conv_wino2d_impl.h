@@ -467,14 +467,20 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const int step = 24 / cnt, at = cnt == 1 ? 13 : 5;
     return (g % step == at && g / step < cnt) ? g / step : -1;
   };
-  auto chunk = [&](int kc, auto h_c, auto first_c) {
+  auto chunk = [&](int kc, auto h_c, auto first_c, auto last_c) {
     constexpr int H = decltype(h_c)::value;
     constexpr bool FIRST = decltype(first_c)::value != 0;   // the first chunk of a tile: its k = 0 MFMAs start the accumulators
+    // The two chunks of the LAST super-chunk (round 6): no weight requests (chunk kc + 2 does not exist - they used to fetch the last slab again,
+    // and the epilogue began by waiting for those twelve loads to return: its registers overlay fbg), no DMA, and in its second chunk no barrier
+    // (nothing to publish), no fragment reads and no transforms (they prepared chunk kc + 1 for nobody).  Same MFMAs in the same order.
+    // (Chained tiles run on into the next tile: no last chunk there.)
+    constexpr bool LAST = decltype(last_c)::value != 0 && !CHAIN;
+    constexpr bool PREP = !(LAST && H == 1);                // this chunk prepares the fragments of chunk kc + 1
     using RH = std::integral_constant<int, 1 - H>;
     const int rs = H == 0 ? st_s : st_n;   // stage of chunk kc + 1
     f2(&Ac)[6][2] = A[H];
     f2(&An)[6][2] = A[1 - H];
-    if constexpr (H == 1) {
+    if constexpr (H == 1 && !LAST) {
       // This wave's requests for super-chunk s + 1 are older than the weight requests of the last chunks (in-order return): the last
       // one went out in a gap of chunk kc - 3, at least 14 weight requests ago (s + 1 < 3: in the prologue, behind it DMA requests
       // and the 6 weight requests of chunk 0).  Everybody else's are published by the barrier.
@@ -490,7 +496,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       dma_on = CHAIN ? gs + NS < gtot : (kc >> 1) + NS < sc1;
       st_dma = st_s;
     }
-    const unsigned so2 = slab(kc + 2);
+    const unsigned so2 = LAST ? 0u : slab(kc + 2);
     __builtin_amdgcn_sched_barrier(0);
     auto gap = [&](auto g_c) {
       constexpr int g = decltype(g_c)::value;
@@ -502,15 +508,16 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       } else {
         acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fbg[H][j][k], Ac[j][k >> 1][k & 1], acc[j], 0, 0, 0);
       }
-      if constexpr ((FLAGS & W2D_DBG_NOB) == 0) {
+      if constexpr ((FLAGS & W2D_DBG_NOB) == 0 && !LAST) {
         if constexpr (k == 3) fbg[H][j] = conv_buf_load(brsrc, bvoff, so2 + (unsigned)j * 1024u);   // consumed: chunk kc + 2's slab into the same registers
       }
-      if constexpr ((FLAGS & W2D_DBG_NORD) == 0) {
+      if constexpr ((FLAGS & W2D_DBG_NORD) == 0 && PREP) {
         if constexpr (g == 0) read_row(d, ix_a, rs, RH{});
         if constexpr (!XF && g == 1) read_row(d2, ix_b, rs, RH{});
         if constexpr (XF && g == 10) read_row(d, ix_b, rs, RH{});
       }
-      if constexpr (!XF) {
+      if constexpr (!PREP) {
+      } else if constexpr (!XF) {
         if constexpr (g >= 4 && g < 10) {   // y combine of pixel g - 4: two packed operations
           constexpr int jj = g - 4;
 #pragma unroll
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
           }
         }
       }
-      if constexpr ((FLAGS & W2D_DBG_NODMA) == 0) {   // a DMA request in a gap without fragment reads
+      if constexpr ((FLAGS & W2D_DBG_NODMA) == 0 && !LAST) {   // a DMA request in a gap without fragment reads
         constexpr int CNT = H == 1 ? P1 : P0, N0 = H == 1 ? 0 : P1;
         constexpr int idx = dma_slot(g, CNT);
         if constexpr (idx >= 0) {
@@ -728,11 +735,18 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       const int tr = g - img * tpi;
       y0 = (tr / ntx) * TH; x0 = (tr % ntx) * PXW;
     }
-    chunk(kc0, C0{}, C1{});
-    chunk(kc0 + 1, C1{}, C0{});
-    for (int kc = kc0 + 2; kc < kc1; kc += 2) {
-      chunk(kc, C0{}, C0{});
-      chunk(kc + 1, C1{}, C0{});
+    chunk(kc0, C0{}, C1{}, C0{});
+    chunk(kc0 + 1, C1{}, C0{}, C0{});
+    const int kc_end = CHAIN ? kc1 : kc1 - 2;
+    for (int kc = kc0 + 2; kc < kc_end; kc += 2) {
+      chunk(kc, C0{}, C0{}, C0{});
+      chunk(kc + 1, C1{}, C0{}, C0{});
+    }
+    if constexpr (!CHAIN) {
+      if (nsc > 1) {   // (a K range of one super-chunk - K = 16, or a split's remainder - ends with the ordinary pair above)
+        chunk(kc1 - 2, C0{}, C0{}, C1{});
+        chunk(kc1 - 1, C1{}, C0{}, C1{});
+      }
     }
     if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { if (ti + 1 == nt) tm2 = __builtin_readcyclecounter(); }
     epilogue();
