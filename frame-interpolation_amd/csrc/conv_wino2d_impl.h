@@ -62,7 +62,7 @@ enum { W2D_F_SQ = 128,         // the 32 units of a tile as 8 unit rows x 4 unit
        W2D_DBG_NOB = 1024,     // no weight requests in the K loop
        W2D_DBG_NOBAR = 2048,   // no barrier in the K loop
        W2D_DBG_NORD = 4096,    // no fragment reads in the K loop
-       W2D_DBG_TIME = 8192 };  // wave 0 of every workgroup writes s_memtime at kernel entry / first MFMA / last MFMA / exit to
+       W2D_DBG_TIME = 8192 };  // wave 0 of every workgroup writes s_memtime at kernel entry / first MFMA / last MFMA / exit (and three stamps inside the epilogue) to
                                // p.part[workgroup * 16 ..], behind the first DMA request / its own stage-0 share / the first barrier, and the
                                // cycles it spent in the K loop's s_waitcnt + barrier pairs (slot 7)
                                // (tools/w2d_bench.hip prints the averages)
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   const int l31 = lane & 31, half = lane >> 5;
   const int mu = wv & 3, ng = wv >> 2;
 
-  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tmA = 0, tmB = 0, tmC = 0, tmW = 0;
+  unsigned long long tm0 = 0, tm1 = 0, tm2 = 0, tmA = 0, tmB = 0, tmC = 0, tmW = 0, tmE1 = 0, tmE2 = 0, tmE3 = 0;
   unsigned long long rt0 = 0;
   if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { rt0 = __builtin_amdgcn_s_memrealtime(); tm0 = __builtin_readcyclecounter(); }
 
@@ -600,7 +600,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     int te = (int)threadIdx.x;
     if constexpr (CHAIN) asm volatile("" : "+v"(te));
     const int t = te, lane = t & 63, l31 = lane & 31, half = lane >> 5;
-    if constexpr (!CHAIN) __syncthreads();   // the exchange buffers overlay the stages (the last chunk prepared fragments nobody uses: its reads are done)
+    if constexpr (!CHAIN) __syncthreads();   // the exchange buffers overlay the stages (every wave's fragment reads are done)
+    if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmE1 = __builtin_readcyclecounter();
                                              // (chained: they lie behind the stages, which already hold the next tile's first super-chunks; a buffer's
                                              // next writers - round jx of the NEXT tile - are a whole K loop of barriers behind its last readers)
     float o[4][16];
@@ -664,6 +665,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
         write_round(jx, xw);
         __syncthreads();
       }
+      if constexpr ((FLAGS & W2D_DBG_TIME) != 0) { if (jx == 0) tmE2 = __builtin_readcyclecounter(); if (jx == 3) tmE3 = __builtin_readcyclecounter(); }
       const bf4 m0 = xw[ridx], m1 = xw[ridx + 256], m2 = xw[ridx + 512], m3 = xw[ridx + 768];
       // Packed, and without compare / select: max(v, slope v) is leaky_relu(0.2) for slope = 0.2 and v itself for slope = 1 (same bits as the
       // v > 0 ? v : 0.2 v form, NaN and -0 included); 24 instead of 46 vector instructions per round (they are taken from the matrix pipe of
@@ -770,6 +772,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3; o8[4] = tmA; o8[5] = tmB; o8[6] = tmC; o8[7] = tmW;
       o8[8] = rt0; o8[9] = __builtin_amdgcn_s_memrealtime();
       o8[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+      o8[11] = tmE1; o8[12] = tmE2; o8[13] = tmE3;   // epilogue: behind its entry barrier / behind the barriers of exchange rounds 0 and 3
     }
   }
 }
