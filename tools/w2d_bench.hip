@@ -346,9 +346,9 @@ int main(int argc, char** argv) {
                            ea / nwg, eb / nwg, ec / nwg, ed / nwg);
         // one machine-readable line per timed launch (tools/w2d_idle_budget.py): per-workgroup averages in shader cycles, per-CU span / summed
         // workgroup lifetimes, the clock, and the event time of this variant's fastest repetition
-        printf("   [time-json] {\"shape\": \"%s\", \"NB\": %d, \"H\": %d, \"W\": %d, \"C\": %d, \"Cout\": %d, \"bn\": %d, \"nwg\": %zu, \"prologue\": %.1f, \"loop\": %.1f, \"wait\": %.1f, "
+        printf("   [time-json] {\"variant\": \"%s\", \"shape\": \"%s\", \"NB\": %d, \"H\": %d, \"W\": %d, \"C\": %d, \"Cout\": %d, \"bn\": %d, \"nwg\": %zu, \"prologue\": %.1f, \"loop\": %.1f, \"wait\": %.1f, "
                "\"epilogue\": %.1f, \"life\": %.1f, \"ncu\": %zu, \"span_max\": %.0f, \"span_avg\": %.0f, \"cu_busy_avg\": %.0f, \"wg_per_cu_min\": %d, \"wg_per_cu_max\": %d, \"ghz\": %.4f, \"ms\": %.5f}\n",
-               sh.name, sh.NB, sh.H, sh.W, sh.C, sh.Cout, v.bn, nwg, pro / nwg, loop / nwg, wait / nwg, epi / nwg, life / nwg, cus.size(), span_max, span_avg, busy_avg, n_min, n_max, ghz, best);
+               v.name, sh.name, sh.NB, sh.H, sh.W, sh.C, sh.Cout, v.bn, nwg, pro / nwg, loop / nwg, wait / nwg, epi / nwg, life / nwg, cus.size(), span_max, span_avg, busy_avg, n_min, n_max, ghz, best);
         // busy share of one CU slot: follow the workgroups that ran on the CU of workgroup 0 (same hw_id CU/SE bits and XCC)
       }
       const bool abl = v.fam < 0;

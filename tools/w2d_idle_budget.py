@@ -46,19 +46,20 @@ def run(args):
     exe = os.path.join(ROOT, 'tools', 'bin', 'w2d_bench')
     with open(args.out, 'w') as out:
         for (NB, H, W, C, Cout), tags in sorted(shapes.items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[0][3] * kv[0][4]):
-            cmd = [exe, str(args.reps), '-2', '=w2d 64 time,=w2d 32 time,=w2d 64,=w2d 32', str(NB), str(H), str(W), str(C), str(Cout)]
+            cmd = [exe, str(args.reps), '-2', '=w2d 64 time,=w2d 32 time,=w2d 32 ns2 time,=w2d 64,=w2d 32,=w2d 32 ns2 plain', str(NB), str(H), str(W), str(C), str(Cout)]
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
             plain = {}
             for line in r.stdout.splitlines():
                 s = line.strip()
-                if s.startswith('w2d 64 ') or s.startswith('w2d 32 '):
-                    name = ' '.join(s.split()[:3]) if s.split()[2] == 'time' else ' '.join(s.split()[:2])
-                    plain[name] = float(s.split('min')[1].split('ms')[0])
+                if (s.startswith('w2d 64 ') or s.startswith('w2d 32 ')) and ' min ' in s:
+                    plain[s.split(' min ')[0].strip()] = float(s.split('min')[1].split('ms')[0])
             for line in r.stdout.splitlines():
                 if '[time-json]' in line:
                     d = json.loads(line.split('[time-json]')[1])
                     d['tags'] = tags
-                    d['plain_ms'] = plain.get(f'w2d {d["bn"]}')
+                    # the un-instrumented twin of the timed variant: 'w2d 64 time' -> 'w2d 64', 'w2d 32 ns2 time' -> 'w2d 32 ns2 plain' (two DMA stages)
+                    twin = d.get('variant', f'w2d {d["bn"]} time').replace(' time', '')
+                    d['plain_ms'] = plain.get(twin + ' plain' if 'ns2' in twin else twin)
                     out.write(json.dumps(d) + '\n')
                     out.flush()
             print(NB, H, W, C, Cout, plain, flush=True)
@@ -101,7 +102,7 @@ def table(args):
         ms = d.get('plain_ms') or d['ms']
         n = len(d['tags'])
         sh = {k: b[k] / b['T'] for k in ('mfma', 'prologue', 'wait', 'gap', 'epilogue', 'idle')}
-        print(f"| {key[0]}x{key[1]}x{key[2]}, {key[3]} -> {key[4]} | {n} | 8x32x{d['bn']} | {ms:.3f} | {b['rounds']:.2f} | {sh['mfma']:.3f} | {b['masked']:.3f} | "
+        print(f"| {key[0]}x{key[1]}x{key[2]}, {key[3]} -> {key[4]} | {n} | 8x32x{d['bn']}{' (2 stages)' if 'ns2' in d.get('variant', '') else ''} | {ms:.3f} | {b['rounds']:.2f} | {sh['mfma']:.3f} | {b['masked']:.3f} | "
               f"{sh['prologue']:.3f} | {sh['wait']:.3f} | {sh['gap']:.3f} | {sh['epilogue']:.3f} | {sh['idle']:.3f} | {b['ghz']:.2f} | {b['span_ratio']:.3f} | "
               f"{b['instr_ratio'] or float('nan'):.3f} |")
         for c in classes:
