@@ -142,6 +142,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // (b) A lane's slot entries come from w2d_slot_table (above), requested first of all.
   int aH = p.H, aW = p.W, aNB = p.NB, aCtot = p.Ctot, aKsplit = p.ksplit, aNseg = p.nseg, aChain = p.chain;
   unsigned a_tpi = p.mg_tpi, a_ntx = p.mg_ntx, a_nby = p.mg_nby;
+  int ntx_ = p.tl_ntx, tpi_ = p.tl_tpi;
   int aGx = (int)gridDim.x, aGy = (int)gridDim.y;
   const float* aS0ptr = p.seg[0].ptr;
   int aS0stride = p.seg[0].stride, aS0C = p.seg[0].C, aS0boff = p.seg[0].boff, aS0bmod = p.seg[0].bmod;
@@ -153,12 +154,18 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   }
   {
     unsigned long long q0 = (unsigned long long)(uintptr_t)aS0ptr, q1 = (unsigned long long)(uintptr_t)aWptr;
-    asm volatile("" : "+s"(aH), "+s"(aW), "+s"(aNB), "+s"(aCtot), "+s"(aKsplit), "+s"(aNseg), "+s"(aChain), "+s"(a_tpi), "+s"(a_ntx), "+s"(a_nby),
+    asm volatile("" : "+s"(aH), "+s"(aW), "+s"(aNB), "+s"(aCtot), "+s"(aKsplit), "+s"(aNseg), "+s"(aChain), "+s"(a_tpi), "+s"(a_ntx), "+s"(a_nby), "+s"(ntx_), "+s"(tpi_),
                       "+s"(aGx), "+s"(aGy), "+s"(q0), "+s"(q1), "+s"(aS0stride), "+s"(aS0C), "+s"(aS0boff), "+s"(aS0bmod));
     aS0ptr = reinterpret_cast<const float*>((uintptr_t)q0);
     aWptr = reinterpret_cast<const float*>((uintptr_t)q1);
   }
-  auto udiv = [](unsigned x, unsigned magic) -> unsigned { return magic ? __umulhi(x, magic) : x; };   // magic = 0: divisor 1
+  // x / d by the launcher's reciprocal; magic = 0 says d = 1 (a scalar select spelled out: hipcc made a branch around the s_mul_hi_u32)
+  auto udiv = [](unsigned x, unsigned magic) -> unsigned {
+    unsigned q;
+    const unsigned h = __umulhi(x, magic);
+    asm("s_cmp_eq_u32 %2, 0\n\ts_cselect_b32 %0, %1, %3" : "=s"(q) : "s"(x), "s"(magic), "s"(h) : "scc");
+    return q;
+  };
   int bx = blockIdx.x, by = blockIdx.y;
   if constexpr ((FLAGS & CONV_B_XCD_M) != 0) {
     const int nbx = aGx, nby = aGy;
@@ -177,8 +184,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // are requested by the ordinary in-loop DMA / weight stream of the current tile (the cursor simply runs on: no burst in front of
   // the epilogue, which is what sank round 4's attempt), land during its last chunks and its epilogue, and the next K loop starts
   // right behind the epilogue.  The exchange buffers then cannot overlay the stages: they lie behind them.
-  const int ntx = (aW + PXW - 1) / PXW, nty = (aH + TH - 1) / TH;
-  const int tpi = ntx * nty;                                    // tiles per image
+  const int ntx = ntx_, tpi = tpi_;                             // tiles per row, per image (the launcher's: (W + PXW - 1) / PXW, x (H + TH - 1) / TH)
   const int chain = CHAIN ? (aChain > 1 ? aChain : 1) : 1;
   const int g0 = bx * chain;
   const int nt = CHAIN ? min(chain, aNB * tpi - g0) : 1;       // tiles of this workgroup
@@ -227,15 +233,16 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       // rpk = the table entry, or ~0 where the slot's pixel lies outside the image: nothing to do for a tile whose halo lies inside (a scalar
       // test; the buffer resource of a segment starts at the halo patch's first pixel (c_y0 - 1, c_x0 - 1): offsets count from there)
       const bool inside = c_y0 >= 1 && c_y0 + TH + 1 <= H && c_x0 >= 1 && c_x0 + PXW + 1 <= W;
+      if (inside) {   // (one branch for all requests: hipcc tested `inside` once per request)
 #pragma unroll
-      for (int n = 0; n < IPW; ++n) {
-        const unsigned tv = rtab[n];
-        unsigned v = tv;
-        if (!inside) {
+        for (int n = 0; n < IPW; ++n) rpk[n] = rtab[n];
+      } else {
+#pragma unroll
+        for (int n = 0; n < IPW; ++n) {
+          const unsigned tv = rtab[n];
           const unsigned y = (unsigned)(c_y0 - 1) + (tv >> 24), x = (unsigned)(c_x0 - 1) + ((tv >> 8) & 255u);   // (wraps below 0: fails the unsigned bound;
-          v = ((y < (unsigned)H) & (x < (unsigned)W)) ? tv : OOB;                                                //  a padding slot: row 255)
+          rpk[n] = ((y < (unsigned)H) & (x < (unsigned)W)) ? tv : OOB;                                           //  a padding slot: row 255)
         }
-        rpk[n] = v;
       }
     }
   };
@@ -818,6 +825,7 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   q.mg_nby = magic(grid.y, (unsigned long long)grid.x * grid.y);
   q.mg_tpi = magic((unsigned long long)ntx * nty, (unsigned long long)ntiles + chain);
   q.mg_ntx = magic(ntx, (unsigned long long)ntx * nty);
+  q.tl_ntx = ntx; q.tl_tpi = ntx * nty;
   if (!exact) return hipErrorInvalidValue;   // (> 2^32 / tiles-per-image workgroups: no plan comes near)
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds + (size_t)conv_wino2d_debug_extra_lds(), s, q);
   return hipGetLastError();

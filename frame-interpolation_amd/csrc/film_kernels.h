@@ -65,6 +65,7 @@ struct ConvParams {
   // the grid - the workgroup -> (image, tile row, tile column, channel block) decomposition then costs three s_mul_hi_u32 instead of three
   // 40-instruction integer divisions in front of the first DMA request (0: divide; conv_wino2d_impl.h, "prologue diet")
   unsigned mg_tpi, mg_ntx, mg_nby;
+  int tl_ntx, tl_tpi;   // ... and the tiles per row / per image themselves
   // Fused AveragePooling2D(2, 2) of the output (feature_extractor.py:138-146: every sub-extractor stage but the last
   // is followed by a pool), conv_wino43_kernel's 64-pixel tiles only: the epilogue also writes
   // pool_out[img][y/2][x/2][n] = (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25 (pool_vec_kernel's order) from
