@@ -137,12 +137,12 @@ static hipError_t launch_wino43(const ConvParams& p, int shape, hipStream_t s) {
 template <int F>
 static hipError_t launch_wino2d(const ConvParams& p, int shape, hipStream_t s) {
   switch (shape) {
-    case W2D_8x64: return conv_wino2d_launch<64, F>(p, s);
-    case W2D_8x32: return conv_wino2d_launch<32, F>(p, s);
-    case W2D_8x32_S2: return conv_wino2d_launch<32, F, 2>(p, s);
-    case W2D_16x64: return conv_wino2d_launch<64, F | W2D_F_SQ>(p, s);
-    case W2D_16x32: return conv_wino2d_launch<32, F | W2D_F_SQ>(p, s);
-    case W2D_16x32_S2: return conv_wino2d_launch<32, F | W2D_F_SQ, 2>(p, s);
+    case W2D_8x64: return conv_wino2d_launch_any<64, F>(p, s);
+    case W2D_8x32: return conv_wino2d_launch_any<32, F>(p, s);
+    case W2D_8x32_S2: return conv_wino2d_launch_any<32, F, 2>(p, s);
+    case W2D_16x64: return conv_wino2d_launch_any<64, F | W2D_F_SQ>(p, s);
+    case W2D_16x32: return conv_wino2d_launch_any<32, F | W2D_F_SQ>(p, s);
+    case W2D_16x32_S2: return conv_wino2d_launch_any<32, F | W2D_F_SQ, 2>(p, s);
     default: return hipErrorInvalidValue;
   }
 }

@@ -53,6 +53,10 @@ enum { W2D_F_SQ = 128,         // the 32 units of a tile as 8 unit rows x 4 unit
                                // four rounds of reads / stores (instead of a barrier per round on two buffers); 64 KB (32 channels) / 128 KB (64) of LDS, not with
                                // the fused 1x1.  Stand-alone -2..-12 % for the 8 x 32 tiles, +5..7 % for the 32-channel 16 x 16 ones; in the engine nothing
                                // (same-box A/B: conv_wino2d_kernel 29.18 vs 29.16-29.6 ms per forward, the K > 528 layers slower): profiles/r06_w2d_epilogue_one_barrier.log
+       W2D_F_XEPI = 8,         // the instantiation that can do split-K (raw partial sums), the fused AveragePooling2D and the fused 1x1 convolution (round 6): the launcher
+                               // refuses those ConvParams without it, and the plain instantiation carries none of their code - per exchange round of the epilogue
+                               // ~35 instructions of tests, branches and register copies that 45 of the 56 layers of a plan never need, each of which waits for an
+                               // issue slot behind the co-resident workgroup's K loop (profiles/r06_w2d_plain_epilogue.log)
        W2D_F_CHAIN = 64,       // a workgroup walks ConvParams::chain consecutive pixel tiles (same output channels): the DMA cursor and the weight
                                // requests run on into the next tile while this one finishes, the epilogue's exchange buffers lie BEHIND the stages
                                // (see "chained tiles" below).  Same sums, same bits.
@@ -117,6 +121,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   static_assert(w2d_quotient_exact(RP4, NREQ * 64) && w2d_quotient_exact(MO4, RP4) && w2d_quotient_exact(CO4, MO4), "slot quotients");
   static_assert(HR * RP4 <= STAGE4, "stage size");
   constexpr bool XF = (FLAGS & W2D_F_XFIRST) != 0;
+  constexpr bool XE = (FLAGS & W2D_F_XEPI) != 0;
   constexpr unsigned OOB = 0xFFFFFFFFu;
 
   extern __shared__ __attribute__((aligned(1024))) float smem[];  // [stage 0][stage 1][stage 2]; the epilogue reuses it as the exchange buffer
@@ -253,7 +258,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     if (sbmod && be >= sbmod) be -= sbmod;
     // (the finished pointer through readfirstlane: should hipcc ever reload `p` with vector loads - it does behind an atomic - a buffer
     // resource in VGPRs cannot feed the DMA statement - nor a buffer load without a waterfall loop)
-    rrsrc = conv_make_rsrc(uniform_ptr(sptr + (((long long)be * aH + (c_y0 - 1)) * aW + (CHAIN ? 0 : c_x0 - 1)) * sstride));
+    const int spix = (be * aH + (c_y0 - 1)) * aW + (CHAIN ? 0 : c_x0 - 1);   // (32 bits, may be negative at the first tile; x the pixel pitch in 64)
+    rrsrc = conv_make_rsrc(uniform_ptr(sptr + (long long)spix * sstride));
     const unsigned st4 = (unsigned)sstride * 4u;
     if constexpr (CHAIN) {
 #pragma unroll
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
   // activation.  The planner uses it for the K >= 768 layers of levels with <= 4096 pixels, whose workgroups do not fill the chip (36x60:
   // 640 workgroups on 512 slots); on the 72x120 level (2304 workgroups = 4.5 rounds) two K ranges gained 2-4 % stand-alone and nothing in
   // the forward (profiles/r05_w2d_splitk.log): not used there.
-  const int ksp = aKsplit > 1 ? aKsplit : 1;
+  const int ksp = XE && aKsplit > 1 ? aKsplit : 1;
   const int nsc_all = aCtot >> 4;
   int sc0 = 0, sc1 = nsc_all;
   if (ksp > 1) {   // (a uniform branch, 32-bit quotients: 460 instead of 740 instructions between kernel entry and the first DMA request of
@@ -629,15 +635,23 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     const int rng = t >> 8, run = (t >> 3) & 31, rcg = t & 7;   // reader: channel tile, unit, 4-channel group
     const int ridx = rng * 1024 + run * 8 + (rcg ^ (run & 7));  // + mu * 256
     const int nrd = n0 + rng * 32 + rcg * 4;
-    const bool rawsum = ksp > 1;   // split-K: no bias, no activation, [split][pixel][Cout]
-    const float b0 = rawsum ? 0.f : p.bias[nrd], b1 = rawsum ? 0.f : p.bias[nrd + 1], b2 = rawsum ? 0.f : p.bias[nrd + 2], b3 = rawsum ? 0.f : p.bias[nrd + 3];
+    const bool rawsum = XE && ksp > 1;   // split-K: no bias, no activation, [split][pixel][Cout]
+    const bool has_pw = XE && p.pw_out != nullptr;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (!rawsum) { const float* const bp = p.bias + nrd; b0 = bp[0]; b1 = bp[1]; b2 = bp[2]; b3 = bp[3]; }   // (one branch: four ternaries were four)
     const int oy = y0 + 2 * (run / QW), ox = x0 + 4 * (run % QW);
     const int ostr = rawsum ? p.Cout : p.ostride;
     const float slope = (p.leaky && !rawsum) ? 0.2f : 1.f;
     // (the tile's corner in 64-bit SCALAR arithmetic, the thread's pixel inside the tile with 24-bit multiplies: the one 64-bit expression
     // was six v_mul_lo_u32 + three v_mad_u64_u32, quarter rate, per pointer; 8 rows x W x the pixel pitch < 2^31: the launcher)
     const int dyo = 2 * (run / QW), dxo = 4 * (run % QW), nth = rng * 32 + rcg * 4;
-    float* const ocorner = (rawsum ? p.part + (size_t)blockIdx.z * p.M * p.Cout : p.out) + (((size_t)img * p.H + y0) * p.W + x0) * ostr + n0;
+    // (the corner's PIXEL index in 32 bits - a launch has fewer than 2^31 pixels, the launcher checks - then one 32 x 32 -> 64-bit product with the pixel
+    // pitch: the all-64-bit expression was ~30 scalar instructions per pointer, and with two workgroups per CU every instruction outside the K loop waits
+    // ~18 cycles for its issue slot)
+    const int cpix = (img * p.H + y0) * p.W + x0;
+    float* obase = p.out;
+    if (rawsum) { asm volatile(""); obase = p.part + (size_t)blockIdx.z * p.M * p.Cout; }   // (the empty statement keeps it a branch: hipcc computed the 64-bit product for every launch)
+    float* const ocorner = obase + ((long long)cpix * ostr + n0);
     float* const orow = ocorner + (__umul24(__umul24(dyo, p.W) + dxo, ostr) + nth);
     // Fused AveragePooling2D(2, 2) of the activated output (ConvParams::pool_out; H, W even): the thread holds rows 2k, 2k + 1 of its
     // unit; x = 4 q + jx pairs up over two rounds: (((o(y,x) + o(y,x+1)) + o(y+1,x)) + o(y+1,x+1)) * 0.25, pool_vec_kernel's order.
@@ -645,12 +659,16 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     // buffers instead of to `out` (68: 16-byte rows whose float4 pieces fall into 16 different bank groups for 16 consecutive pixels -
     // conflict-free ds_write_b128 from the (unit, channel group) threads and ds_read_b128 from the pixel threads); the 1x1 weights go
     // to LDS once as [c][4]; thread = pixel then sums its 64 channels, one fma chain per output in channel order (conv_pw_kernel's).
-    float* const pool_corner = p.pool_out ? p.pool_out + (((size_t)img * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1)) * p.pool_ostride + n0 : nullptr;
-    float* const pool_base = p.pool_out ? pool_corner + (__umul24(__umul24(dyo >> 1, p.W >> 1) + (dxo >> 1), p.pool_ostride) + nth) : nullptr;
+    float* pool_base = nullptr;
+    if (XE && p.pool_out) {
+      asm volatile("");
+      const int ppix = (img * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1);
+      pool_base = p.pool_out + ((long long)ppix * p.pool_ostride + n0) + (__umul24(__umul24(dyo >> 1, p.W >> 1) + (dxo >> 1), p.pool_ostride) + nth);
+    }
     constexpr int PWS = 68;
     float* const pwt = smem + 2 * XB4 * 4;   // (never with W2D_F_CHAIN: the launcher refuses the fused 1x1 there)
     float* const pww = pwt + TH * PXW * PWS;   // [64][4]
-    if (p.pw_out != nullptr && t < 256) pww[t] = (t & 3) < p.pw_cout ? p.pw_w[(t >> 2) * p.pw_cout + (t & 3)] : 0.f;   // (published by the rounds' barriers)
+    if (has_pw && t < 256) pww[t] = (t & 3) < p.pw_cout ? p.pw_w[(t >> 2) * p.pw_cout + (t & 3)] : 0.f;   // (published by the rounds' barriers)
     bf4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = {0.f, 0.f, 0.f, 0.f};
     auto write_round = [&](int jx, bf4* xw) {
   #pragma unroll
@@ -687,13 +705,13 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
         set_pair(r0, q, f2{max1(v0[0], s0[0]), max1(v0[1], s0[1])});   // (asm: fmaxf on the results of asm statements costs two canonicalising
         set_pair(r1, q, f2{max1(v1[0], s1[0]), max1(v1[1], s1[1])});   // v_max_f32 x, x, x more per element)
       }
-      if (p.pw_out == nullptr) {
+      if (!has_pw) {
         if (ox + jx < p.W) {
           float* const o0 = orow + (size_t)jx * ostr;
           if (oy < p.H) *reinterpret_cast<bf4*>(o0) = r0;
           if (oy + 1 < p.H) *reinterpret_cast<bf4*>(o0 + (size_t)p.W * ostr) = r1;
         }
-        if (pool_base != nullptr) {
+        if (XE && pool_base != nullptr) {
           if (jx & 1) {
             bf4 pv;
   #pragma unroll
@@ -709,7 +727,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
         *reinterpret_cast<bf4*>(tr + PXW * PWS) = r1;
       }
     }
-    if (p.pw_out != nullptr) {
+    if (has_pw) {
       __syncthreads();
       if (t < TH * PXW) {
         const int y = y0 + t / PXW, x = x0 + (t % PXW);
@@ -792,6 +810,7 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   // NS stages of 24 KB; the exchange buffers (2 x BN / 32 x 16 KB) fit inside them - or, chained, lie behind them (80 KB for the 32-channel
   // tile on two stages: two workgroups per CU; 136 KB for the 64-channel one); the fused 1x1 adds its [256][68] tile and its weights
   constexpr bool E1 = (FLAGS & W2D_F_EPI1) != 0 && !CHAIN;
+  if (!(FLAGS & W2D_F_XEPI) && (p.ksplit > 1 || p.pool_out || p.pw_out)) return hipErrorInvalidValue;   // (conv_wino2d_launch_any picks the instantiation)
   if (E1 && p.pw_out) return hipErrorInvalidValue;   // (the fused 1x1's pixel tile lies behind TWO exchange buffers)
   const size_t lds = CHAIN ? (size_t)NS * 24 * 1024 + (size_t)2 * (BN / 32) * 16 * 1024
                            : p.pw_out ? (size_t)2 * (BN / 32) * 16 * 1024 + 256 * 68 * 4 + 1024
@@ -804,6 +823,11 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
     if (BN != 64 || p.Cout != 64 || p.pool_out || p.pw_cout < 1 || p.pw_cout > 4) return hipErrorInvalidValue;
   } else if (p.ostride % 4 || (reinterpret_cast<uintptr_t>(p.out) & 15)) return hipErrorInvalidValue;   // dwordx4 stores
   if (p.pool_out && ((p.H | p.W) & 1 || p.pool_ostride % 4 || (reinterpret_cast<uintptr_t>(p.pool_out) & 15))) return hipErrorInvalidValue;
+  {   // pixel indices in 32 bits (tile corners, halo corners: one more row)
+    long long nimg = p.NB;
+    for (int i = 0; i < p.nseg; ++i) nimg = std::max<long long>(nimg, (long long)p.seg[i].bmod);
+    if ((nimg + 1) * p.H * p.W >= (1ll << 31)) return hipErrorInvalidValue;
+  }
   if (p.W <= 0 || p.H <= 0 || p.W >= (1 << 20) || p.ostride >= (1 << 22) || p.pool_ostride >= (1 << 22) || p.Cout >= (1 << 22) ||
       (long long)8 * p.W * (p.ostride > p.Cout ? p.ostride : p.Cout) >= (1ll << 31)) return hipErrorInvalidValue;   // 24-bit multiplies of the DMA offsets: 10 halo rows x W pixels < 2^24
   for (int i = 0; i < p.nseg; ++i)
@@ -829,4 +853,11 @@ hipError_t conv_wino2d_launch(const ConvParams& p, hipStream_t s) {
   if (!exact) return hipErrorInvalidValue;   // (> 2^32 / tiles-per-image workgroups: no plan comes near)
   hipLaunchKernelGGL(kern, grid, dim3(NT), lds + (size_t)conv_wino2d_debug_extra_lds(), s, q);
   return hipGetLastError();
+}
+
+// the instantiation a ConvParams block needs: the extended epilogue only for split-K, fused pooling, fused 1x1
+template <int BN, int FLAGS, int NS = 3>
+hipError_t conv_wino2d_launch_any(const ConvParams& p, hipStream_t s) {
+  if (p.ksplit > 1 || p.pool_out || p.pw_out) return conv_wino2d_launch<BN, FLAGS | W2D_F_XEPI, NS>(p, s);
+  return conv_wino2d_launch<BN, FLAGS, NS>(p, s);
 }

@@ -125,7 +125,7 @@ template <int BN, int S>
 static hipError_t w2d_split(const ConvParams& p0, hipStream_t st) {
   ConvParams p = p0;
   p.ksplit = S; p.part = g_part;
-  const hipError_t e = conv_wino2d_launch<BN, 4>(p, st);
+  const hipError_t e = conv_wino2d_launch<BN, 4 | W2D_F_XEPI>(p, st);
   if (e != hipSuccess) return e;
   const unsigned units = (unsigned)p.M * (unsigned)(p.Cout >> 2);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((units + 255) / 256), dim3(256), 0, st, p.part, p.bias, p.out, p.M, p.Cout, p.ostride, S, p.leaky);
@@ -158,6 +158,8 @@ static Variant variants[] = {
     W2C("32 ns2 ch1", 32, 2, 1), W2C("32 ns2 ch2", 32, 2, 2), W2C("32 ns2 ch4", 32, 2, 4), W2C("32 ns2 ch8", 32, 2, 8),
     W2C("64 ns3 ch1", 64, 3, 1), W2C("64 ns3 ch2", 64, 3, 2), W2C("64 ns3 ch4", 64, 3, 4), W2C("64 ns3 ch8", 64, 3, 8),
     {"w2d 32 ns2 plain", 32, 1, conv_wino2d_launch<32, 4, 2>},
+    {"w2d 32 ns2 xe", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_XEPI, 2>}, {"w2d 32 ns2 sq xe", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ | W2D_F_XEPI, 2>},
+    {"w2d 64 ns3 xe", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_XEPI, 3>},
     {"w2d 32 ns2 e1", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_EPI1, 2>}, {"w2d 32 ns2 sq e1", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ | W2D_F_EPI1, 2>},
     {"w2d 64 ns3 e1", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_EPI1, 3>}, {"w2d 64 ns3 sq e1", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_SQ | W2D_F_EPI1, 3>},
     {"w2d 32 ns2 sq", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ, 2>}, {"w2d 32 ns3 sq", 32, 1, conv_wino2d_launch<32, 4 | W2D_F_SQ, 3>}, {"w2d 64 ns3 sq", 64, 1, conv_wino2d_launch<64, 4 | W2D_F_SQ, 3>},
