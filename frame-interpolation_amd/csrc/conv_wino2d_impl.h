@@ -164,6 +164,8 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     aS0ptr = reinterpret_cast<const float*>((uintptr_t)q0);
     aWptr = reinterpret_cast<const float*>((uintptr_t)q1);
   }
+  unsigned long long tmK = 0, tmT = 0;   // W2D_DBG_TIME: the kernel arguments are here / the slot-table entries are here
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmK = __builtin_readcyclecounter();
   // x / d by the launcher's reciprocal; magic = 0 says d = 1 (a scalar select spelled out: hipcc made a branch around the s_mul_hi_u32)
   auto udiv = [](unsigned x, unsigned magic) -> unsigned {
     unsigned q;
@@ -252,6 +254,13 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
     }
   };
   set_rpk();
+  // Every slot entry is waited for HERE, in front of the first DMA request.  hipcc's s_waitcnt pass does not count the DMA statements (inline asm): it
+  // placed "vmcnt(3) ... vmcnt(0)" for table entries 2..5 BETWEEN them, and with the requests outstanding that the pass does not know of, vmcnt(1) /
+  // vmcnt(0) waited for the first DMA requests to COMPLETE before the fourth and fifth went out - an HBM round trip inside the issue sequence (found
+  // with two more W2D_DBG_TIME stamps: entry -> all six requests issued 6 400 -> 3 000 cycles, profiles/r06_w2d_table_wait.log).
+#pragma unroll
+  for (int n = 0; n < IPW; ++n) asm volatile("" : "+v"(rpk[n]));
+  if constexpr ((FLAGS & W2D_DBG_TIME) != 0) tmT = __builtin_readcyclecounter();
   auto raw_setup_seg_of = [&](const float* sptr, int sstride, int sC, int sboff, int sbmod) {
     rsegC = __builtin_amdgcn_readfirstlane(sC);
     int be = c_img + sboff;
@@ -797,7 +806,7 @@ __global__ __launch_bounds__(4 * (BN / 32) * 64, (BN == 32) ? 2 : 1) void conv_w
       o8[0] = tm0; o8[1] = tm1; o8[2] = tm2; o8[3] = tm3; o8[4] = tmA; o8[5] = tmB; o8[6] = tmC; o8[7] = tmW;
       o8[8] = rt0; o8[9] = __builtin_amdgcn_s_memrealtime();
       o8[10] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-      o8[11] = tmE1; o8[12] = tmE2; o8[13] = tmE3;   // epilogue: behind its entry barrier / behind the barriers of exchange rounds 0 and 3
+      o8[11] = tmE1; o8[12] = tmE2; o8[13] = tmE3; o8[14] = tmK; o8[15] = tmT;   // epilogue: behind its entry barrier / behind the barriers of exchange rounds 0 and 3
     }
   }
 }

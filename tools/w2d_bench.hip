@@ -318,7 +318,7 @@ int main(int argc, char** argv) {
         const size_t nwg = (size_t)sh.NB * ((sh.H + 7) / 8) * ((sh.W + 31) / 32) * (sh.Cout / v.bn);
         std::vector<unsigned long long> tm(nwg * 16);
         CK(hipMemcpy(tm.data(), d_tm, nwg * 128, hipMemcpyDeviceToHost));
-        double pro = 0, loop = 0, epi = 0, pa = 0, pb = 0, pc = 0, wait = 0, life = 0, cyc = 0, rt = 0, ea = 0, eb = 0, ec = 0, ed = 0;
+        double pro = 0, loop = 0, epi = 0, pa = 0, pb = 0, pc = 0, wait = 0, life = 0, cyc = 0, rt = 0, ea = 0, eb = 0, ec = 0, ed = 0, ka = 0, kb = 0;
         // s_memtime counts shader cycles on a counter of the workgroup's own CU group: stamps compare within one CU only.  Per CU (HW_ID bits
         // 8..15 + XCC_ID): its span (first entry .. last exit), the summed lifetimes of its workgroups, how many it ran.
         struct CuAcc { unsigned long long t0 = ~0ull, t1 = 0; double busy = 0; int n = 0; };
@@ -328,6 +328,7 @@ int main(int argc, char** argv) {
           pa += (double)(e[4] - e[0]); pb += (double)(e[5] - e[4]); pc += (double)(e[6] - e[5]);
           pro += (double)(e[1] - e[0]); loop += (double)(e[2] - e[1]); epi += (double)(e[3] - e[2]);
           wait += (double)e[7]; life += (double)(e[3] - e[0]);
+          if (e[14]) { ka += (double)(e[14] - e[0]); kb += (double)(e[15] - e[0]); }
           if (e[11]) { ea += (double)(e[11] - e[2]); eb += (double)(e[12] - e[11]); ec += (double)(e[13] - e[12]); ed += (double)(e[3] - e[13]); }
           cyc += (double)(e[3] - e[0]); rt += (double)(e[9] - e[8]);
           CuAcc& c = cus[(e[10] & 0xFF00ull) | (e[10] >> 32 << 16)];
@@ -344,6 +345,7 @@ int main(int argc, char** argv) {
         const double ghz = rt > 0 ? cyc / rt * 0.1 : 0;   // shader cycles per 10 ns tick of s_memrealtime
         printf("   [time] %zu workgroups on %zu CUs (%d..%d each): prologue %.0f (entry -> first DMA issued %.0f, -> stage 0 landed %.0f, -> barrier passed %.0f, -> fragments of chunk 0 ready)  K loop %.0f (of it s_waitcnt + barrier %.0f)  epilogue %.0f cycles (averages); span per CU max %.0f avg %.0f cycles, clock %.3f GHz\n", nwg, cus.size(), n_min, n_max,
                pro / nwg, pa / nwg, pb / nwg, pc / nwg, loop / nwg, wait / nwg, epi / nwg, span_max, span_avg, ghz);
+        if (ka > 0) printf("   [time] prologue: kernel arguments in registers %.0f cycles after entry, slot-table entries (and the bounds tests) %.0f\n", ka / nwg, kb / nwg);
         if (ea > 0) printf("   [time] epilogue: last MFMA -> entry barrier passed %.0f, -> round 0 published (x inverse, first writes, barrier) %.0f, -> round 3 published %.0f, -> exit %.0f cycles\n",
                            ea / nwg, eb / nwg, ec / nwg, ed / nwg);
         // one machine-readable line per timed launch (tools/w2d_idle_budget.py): per-workgroup averages in shader cycles, per-CU span / summed
