@@ -14,14 +14,14 @@ import re
 
 
 def short(name):
-    m = re.search(r'(conv_buf_kernel|conv_halo_kernel|conv_winox3_kernel|conv_wino43_kernel|conv_wino2d_kernel|conv_wino_kernel|conv_foldx3_kernel|conv_splitk_reduce_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_c3_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
+    m = re.search(r'(conv_buf_kernel|conv_halo_kernel|conv_winox3_kernel|conv_wino43_kernel|conv_wino2d_kernel|conv_fold4_kernel|conv_wino_kernel|conv_foldx3_kernel|conv_splitk_reduce_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_c3_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
                   r'pool_vec_kernel|pool_c3_kernel|flow_up_kernel|flow_add_kernel|pack_flow_kernel|frame_to_tiles_kernel|'
                   r'tiles_to_frame_kernel)', name)
     return m.group(1) if m else None
 
 
 def klass(k):
-    return 'conv_mfma' if k in ('conv_buf_kernel', 'conv_halo_kernel', 'conv_wino_kernel', 'conv_wino43_kernel', 'conv_wino2d_kernel', 'conv_winox3_kernel', 'conv_foldx3_kernel', 'conv_splitk_reduce_kernel',
+    return 'conv_mfma' if k in ('conv_buf_kernel', 'conv_halo_kernel', 'conv_wino_kernel', 'conv_wino43_kernel', 'conv_wino2d_kernel', 'conv_fold4_kernel', 'conv_winox3_kernel', 'conv_foldx3_kernel', 'conv_splitk_reduce_kernel',
                               'conv_halo_split_kernel', 'conv_igemm_kernel', 'conv_c3_kernel') else k.replace('_kernel', '')
 
 

@@ -13,7 +13,7 @@ import sqlite3
 import sys
 from collections import defaultdict
 
-ENGINE = re.compile(r'conv_buf_kernel|conv_halo_kernel|conv_wino43_kernel|conv_wino2d_kernel|conv_wino_kernel|conv_winox3_kernel|conv_foldx3_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_c3_kernel|conv_splitk_reduce_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
+ENGINE = re.compile(r'conv_buf_kernel|conv_halo_kernel|conv_wino43_kernel|conv_wino2d_kernel|conv_fold4_kernel|conv_wino_kernel|conv_winox3_kernel|conv_foldx3_kernel|conv_halo_split_kernel|conv_igemm_kernel|conv_c3_kernel|conv_splitk_reduce_kernel|conv_pw_kernel|flow_head_kernel|warp_vec_kernel|warp_c3_kernel|'
                     r'pool_vec_kernel|pool_c3_kernel|flow_up_kernel|flow_add_kernel|pack_flow_kernel|frame_to_tiles_kernel|'
                     r'tiles_to_frame_kernel')
 
@@ -58,7 +58,7 @@ def main():
               f'{a[3]:.1f} | {100 * a[1] / total:.2f} |')
     conv = sum(a[1] for k, a in agg.items() if k.startswith(('conv_buf', 'conv_halo', 'conv_wino', 'conv_fold', 'conv_igemm', 'conv_c3')))
     nconv = sum(a[0] for k, a in agg.items() if k.startswith(('conv_buf', 'conv_halo', 'conv_wino', 'conv_fold', 'conv_igemm', 'conv_c3')))
-    print(f'\nMFMA conv kernels (conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf, all tile shapes, + the first-layer conv_c3_kernel / conv_igemm_kernel): {nconv / args.forwards:.0f} launches/forward, '
+    print(f'\nMFMA conv kernels (conv_wino2d / conv_fold4 / conv_wino43 / conv_wino / conv_winox3 / conv_halo / conv_halo_split / conv_foldx3 / conv_buf, all tile shapes, + the first-layer conv_c3_kernel / conv_igemm_kernel): {nconv / args.forwards:.0f} launches/forward, '
           f'{conv / args.forwards / 1e3:.3f} ms/forward, average launch {conv / nconv:.1f} us')
 
 
